@@ -1,0 +1,363 @@
+"""CPU oracle for the DEviS evidential U-Net hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32) restatement of the reference algorithm.
+It is the *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing under
+``devis_amd/`` (the product) imports, calls or falls back to it.
+
+Pinning: the reference holds no tests or golden vectors of its own,
+so this restatement is pinned by running the real reference (imported from
+/root/reference on CPU, see ``tests/golden/make_goldens.py``) on seeded inputs
+and asserting bit-equality with this file; the resulting vectors are committed
+under ``tests/golden/``.
+
+It is written functionally (a ``state_dict`` in, tensors out) rather than as
+``nn.Module`` classes; every function cites the reference lines it restates
+(paths relative to /root/reference).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+StateDict = Dict[str, Tensor]
+
+
+# ----------------------------------------------------------------------------
+# 3D residual U-Net  (models/lib/UNet3DZoo.py:243-305)
+# ----------------------------------------------------------------------------
+
+def _conv(sd: StateDict, key: str, x: Tensor, stride: int = 1, pad: int = 1) -> Tensor:
+    fn = F.conv3d if x.dim() == 5 else F.conv2d
+    return fn(x, sd[key + ".weight"], sd[key + ".bias"], stride=stride, padding=pad)
+
+
+def _gn_relu(sd: StateDict, key: str, x: Tensor) -> Tensor:
+    # GroupNorm(8, C) then ReLU: UNet3DZoo.py:12, :39-40
+    return F.relu(F.group_norm(x, 8, sd[key + ".weight"], sd[key + ".bias"], 1e-5))
+
+
+def _bn_relu(sd: StateDict, key: str, x: Tensor, training: bool) -> Tensor:
+    # nn.BatchNorm{2,3}d defaults: eps 1e-5, momentum 0.1; running buffers are
+    # updated in place inside ``sd`` when training (UNet3DZoo.py:149-162).
+    if training:
+        sd[key + ".num_batches_tracked"] += 1
+    y = F.batch_norm(x, sd[key + ".running_mean"], sd[key + ".running_var"],
+                     sd[key + ".weight"], sd[key + ".bias"], training, 0.1, 1e-5)
+    return F.relu(y)
+
+
+def _en_block(sd: StateDict, name: str, x: Tensor) -> Tensor:
+    # EnBlock.forward, UNet3DZoo.py:47-56
+    h = _conv(sd, name + ".conv1", _gn_relu(sd, name + ".bn1", x))
+    h = _conv(sd, name + ".conv2", _gn_relu(sd, name + ".bn2", h))
+    return h + x
+
+
+def _de_block(sd: StateDict, name: str, x: Tensor, training: bool) -> Tensor:
+    # DeBlock.forward, UNet3DZoo.py:156-165 (conv -> BN -> ReLU, twice, + x)
+    h = _bn_relu(sd, name + ".bn1", _conv(sd, name + ".conv1", x), training)
+    h = _bn_relu(sd, name + ".bn2", _conv(sd, name + ".conv2", h), training)
+    return h + x
+
+
+def _de_up_cat(sd: StateDict, name: str, x: Tensor, prev: Tensor) -> Tensor:
+    # DeUp_Cat.forward, UNet3DZoo.py:124-130: 1x1 -> ConvT k2 s2 -> cat(prev, up) -> 1x1
+    h = _conv(sd, name + ".conv1", x, pad=0)
+    h = F.conv_transpose3d(h, sd[name + ".conv2.weight"], sd[name + ".conv2.bias"], stride=2)
+    return _conv(sd, name + ".conv3", torch.cat((prev, h), dim=1), pad=0)
+
+
+def unet3d_forward(sd: StateDict, x: Tensor, training: bool = True) -> Tensor:
+    """Unet.forward, UNet3DZoo.py:276-305.  ``InitConv`` dropout has p=0 (:248)."""
+    h = _conv(sd, "InitConv.conv", x)
+    s1 = _en_block(sd, "EnBlock1", h)
+    h = _conv(sd, "EnDown1.conv", s1, stride=2)
+    h = _en_block(sd, "EnBlock2_1", h)
+    s2 = _en_block(sd, "EnBlock2_2", h)
+    h = _conv(sd, "EnDown2.conv", s2, stride=2)
+    h = _en_block(sd, "EnBlock3_1", h)
+    s3 = _en_block(sd, "EnBlock3_2", h)
+    h = _conv(sd, "EnDown3.conv", s3, stride=2)
+    for i in (1, 2, 3, 4):
+        h = _en_block(sd, "EnBlock4_%d" % i, h)
+    h = _de_block(sd, "DeBlock4", _de_up_cat(sd, "DeUpCat4", h, s3), training)
+    h = _de_block(sd, "DeBlock3", _de_up_cat(sd, "DeUpCat3", h, s2), training)
+    h = _de_block(sd, "DeBlock2", _de_up_cat(sd, "DeUpCat2", h, s1), training)
+    return _conv(sd, "endconv", h, pad=0)
+
+
+# ----------------------------------------------------------------------------
+# 2D U-Net  (models/lib/UNet2DZoo.py:107-259)
+# ----------------------------------------------------------------------------
+
+def _double_conv(sd: StateDict, name: str, x: Tensor, training: bool) -> Tensor:
+    # DoubleConv, UNet2DZoo.py:8-21: Sequential indices 0,1,(2),3,4,(5)
+    h = _bn_relu(sd, name + ".conv.1", _conv(sd, name + ".conv.0", x), training)
+    return _bn_relu(sd, name + ".conv.4", _conv(sd, name + ".conv.3", h), training)
+
+
+def _offset_cat_w(skip: Tensor, up: Tensor, rand_log: Optional[List[Tuple[int, ...]]]) -> Tensor:
+    # Unet2D.offsetCat, UNet2DZoo.py:162-182: pad *width* with torch.rand drawn
+    # from the global CPU generator; (skip, up) channel order.
+    off = abs(skip.size(3) - up.size(3))
+    if off == 1:
+        shape = (up.size(0), up.size(1), up.size(2))
+        add = torch.rand(shape).unsqueeze(3)
+    elif off > 1:
+        shape = (up.size(0), up.size(1), up.size(2), off)
+        add = torch.rand(shape)
+    if off >= 1:
+        if rand_log is not None:
+            rand_log.append(tuple(shape))
+        up = torch.cat([up, add.to(up.device)], dim=3)
+    return torch.cat([skip, up], dim=1)
+
+
+def _offset_cat_drive(skip: Tensor, up: Tensor, rand_log: Optional[List[Tuple[int, ...]]]) -> Tensor:
+    # Unet2DDRIVE.offsetCat, UNet2DZoo.py:239-259: pads H if H differs, else W.
+    if skip.shape[2] != up.shape[2]:
+        shape = (up.size(0), up.size(1), abs(skip.size(2) - up.size(2)), up.size(3))
+        dim = 2
+    elif skip.shape[3] != up.shape[3]:
+        shape = (up.size(0), up.size(1), up.size(2), abs(skip.size(3) - up.size(3)))
+        dim = 3
+    else:
+        return torch.cat([skip, up], dim=1)
+    if rand_log is not None:
+        rand_log.append(tuple(shape))
+    up = torch.cat([up, torch.rand(shape).to(up.device)], dim=dim)
+    return torch.cat([skip, up], dim=1)
+
+
+def unet2d_forward(sd: StateDict, x: Tensor, training: bool = True, drive: bool = False,
+                   rand_log: Optional[List[Tuple[int, ...]]] = None) -> Tensor:
+    """Unet2D.forward (UNet2DZoo.py:130-160) / Unet2DDRIVE.forward (:207-237).
+
+    Returns the raw logits ``c10`` (the ``nn.Softmax()`` at :159 is dead code).
+    """
+    ocat = _offset_cat_drive if drive else _offset_cat_w
+    c1 = _double_conv(sd, "conv1", x, training)
+    c2 = _double_conv(sd, "conv2", F.max_pool2d(c1, 2), training)
+    c3 = _double_conv(sd, "conv3", F.max_pool2d(c2, 2), training)
+    c4 = _double_conv(sd, "conv4", F.max_pool2d(c3, 2), training)
+    c5 = _double_conv(sd, "conv5", F.max_pool2d(c4, 2), training)
+
+    def up(name: str, t: Tensor) -> Tensor:
+        return F.conv_transpose2d(t, sd[name + ".weight"], sd[name + ".bias"], stride=2)
+
+    c6 = _double_conv(sd, "conv6", ocat(c4, up("up6", c5), rand_log), training)
+    c7 = _double_conv(sd, "conv7", ocat(c3, up("up7", c6), rand_log), training)
+    c8 = _double_conv(sd, "conv8", torch.cat([up("up8", c7), c2], dim=1), training)
+    u9 = up("up9", c8)
+    m9 = ocat(c1, u9, rand_log) if drive else torch.cat([u9, c1], dim=1)
+    c9 = _double_conv(sd, "conv9", m9, training)
+    return _conv(sd, "conv10", c9, pad=0)
+
+
+# ----------------------------------------------------------------------------
+# Evidential criteria  (models/criterions.py)
+# ----------------------------------------------------------------------------
+
+def kl_dirichlet(alpha: Tensor, c: int) -> Tensor:
+    """KL(Dir(alpha) || Dir(1)) per row, criterions.py:117-127 (without the hard .cuda())."""
+    s_alpha = torch.sum(alpha, dim=1, keepdim=True)
+    beta = torch.ones((1, c), device=alpha.device)
+    s_beta = torch.sum(beta, dim=1, keepdim=True)
+    ln_b = torch.lgamma(s_alpha) - torch.sum(torch.lgamma(alpha), dim=1, keepdim=True)
+    ln_b_uni = torch.sum(torch.lgamma(beta), dim=1, keepdim=True) - torch.lgamma(s_beta)
+    dg0 = torch.digamma(s_alpha)
+    dg1 = torch.digamma(alpha)
+    return torch.sum((alpha - beta) * (dg1 - dg0), dim=1, keepdim=True) + ln_b + ln_b_uni
+
+
+def soft_label(labels: Tensor, num_class: int) -> Tensor:
+    """get_soft_label, criterions.py:353-370: (N,1,...) int -> (N,...,K) float one-hot."""
+    t = labels.permute(0, 2, 3, 4, 1) if labels.ndim == 5 else labels.permute(0, 2, 3, 1)
+    planes = [torch.eq(t, i * torch.ones_like(t)) for i in range(num_class)]
+    return torch.cat(planes, dim=-1).float()
+
+
+def sdice_loss(preds: Tensor, targets: Tensor) -> Tensor:
+    """SDiceLoss.forward (weight_map=None), criterions.py:226-257."""
+    k = preds.size(1)
+    p = preds.permute(0, 2, 3, 4, 1) if preds.ndim == 5 else preds.permute(0, 2, 3, 1)
+    pred = p.contiguous().view(-1, k)
+    ground = targets.view(-1, k)
+    ref_vol = torch.sum(ground, 0)
+    intersect = torch.sum(ground * pred, 0)
+    seg_vol = torch.sum(pred, 0)
+    dice = (2.0 * intersect + 1e-5) / (ref_vol + seg_vol + 1.0 + 1e-5)
+    return torch.mean(-torch.log(dice))
+
+
+def tversky_dice_loss(preds: Tensor, targets: Tensor) -> Tensor:
+    """DiceLoss.forward (weight=False, reduce, size_average), criterions.py:166-215."""
+    c = preds.size(1)
+    if preds.ndim == 5:
+        preds = preds.permute(0, 2, 3, 4, 1).contiguous().view(-1, c)
+    else:
+        preds = preds.permute(0, 2, 3, 1).contiguous().view(-1, c)
+    targets = targets.view(-1, 1)
+    prob = torch.exp(F.log_softmax(preds, dim=1))
+    smooth = torch.zeros(c, dtype=torch.float32).fill_(0.00001).to(preds.device)
+    mask = torch.zeros(preds.shape).to(preds.device) + 1e-8
+    mask.scatter_(1, targets, 1.)
+    ones = torch.ones(preds.shape).to(preds.device)
+    tp = prob * mask
+    fp = prob * (ones - mask)
+    fn = (ones - prob) * mask
+    a = fp.sum(dim=0) / ((fp.sum(dim=0) + fn.sum(dim=0)) + smooth)
+    a = torch.clamp(a, min=0.2, max=0.8)
+    b = 1 - a
+    num = torch.sum(tp, dim=0).float()
+    den = num + a * torch.sum(fp, dim=0).float() + b * torch.sum(fn, dim=0).float()
+    dice = num / (den + smooth)
+    return (1 - dice).sum() / c
+
+
+def _rows(alpha: Tensor) -> Tensor:
+    # [N,C,...] -> [N*V, C]; criterions.py:436-438
+    a = alpha.view(alpha.size(0), alpha.size(1), -1).transpose(1, 2)
+    return a.contiguous().view(-1, a.size(2))
+
+
+def dce_evidence_loss(p, alpha, c, current_step, lamda_step, total_step, eps,
+                      disentangle, evidence, backbone_pred) -> Tensor:
+    """criterions.py:421-456: returns (NV,1) = L_ace + L_dice + lambda*KL."""
+    sp = p.unsqueeze(1) if alpha.ndim == 5 else p
+    l_dice = sdice_loss(evidence, soft_label(sp, c))
+    alpha = _rows(alpha)
+    s = torch.sum(alpha, dim=1, keepdim=True)
+    e = alpha - 1
+    label = F.one_hot(p, num_classes=c).view(-1, c)
+    l_ace = torch.sum(label * (torch.digamma(s) - torch.digamma(alpha)), dim=1, keepdim=True)
+    coef = min(1, current_step / lamda_step)
+    alp = e * (1 - label) + 1
+    l_kl = coef * kl_dirichlet(alp, c)
+    return l_ace + l_dice + l_kl
+
+
+def dce_evidence_u_loss(p, alpha, c, current_step, lamda_step, total_step, eps,
+                        disentangle, evidence, backbone_pred) -> Tensor:
+    """criterions.py:373-419 (Uncertainty_Loss=True variant)."""
+    sp = p.unsqueeze(1) if alpha.ndim == 5 else p
+    l_dice = tversky_dice_loss(evidence, sp)
+    alpha = _rows(alpha)
+    s = torch.sum(alpha, dim=1, keepdim=True)
+    e = alpha - 1
+    label = F.one_hot(p, num_classes=c).view(-1, c)
+    l_ace = torch.sum(label * (torch.digamma(s) - torch.digamma(alpha)), dim=1, keepdim=True)
+    coef = min(1, current_step / lamda_step)
+    a0 = torch.tensor(0.01, dtype=torch.float32)
+    a_au = a0 * torch.exp(-torch.log(a0) / total_step * current_step)
+    alp = e * (1 - label) + 1
+    l_kl = coef * kl_dirichlet(alp, c)
+    score, cls = torch.max(alpha / s, 1, keepdim=True)
+    u = c / s
+    match = torch.reshape(torch.eq(cls, p.view(-1, 1)).float(), (-1, 1))
+    if disentangle:
+        acc_unc = -torch.log(score * (1 - u) + eps)
+        inacc_cert = -torch.log((1 - score) * u + eps)
+    else:
+        acc_unc = -score * torch.log(1 - u + eps)
+        inacc_cert = -(1 - score) * torch.log(u + eps)
+    l_au = a_au * match * acc_unc + (1 - a_au) * (1 - match) * inacc_cert
+    return l_ace + l_kl + (1 - a_au) * l_dice + l_au
+
+
+def ce_loss(p, alpha, c, global_step, annealing_step) -> Tensor:
+    """criterions.py:130-142 (5-D NCDHW alpha; one-hot permuted to channel dim)."""
+    s = torch.sum(alpha, dim=1, keepdim=True)
+    e = alpha - 1
+    label = F.one_hot(p, num_classes=c).permute(0, 4, 1, 2, 3)
+    a = torch.sum(label * (torch.digamma(s) - torch.digamma(alpha)), dim=1, keepdim=True)
+    coef = min(1, global_step / annealing_step)
+    alp = e * (1 - label) + 1
+    return a + coef * kl_dirichlet(alp, c)
+
+
+def mse_loss(p, alpha, c, global_step, annealing_step=1) -> Tensor:
+    """criterions.py:144-154 (row layout: alpha (NV,K), p (NV,))."""
+    s = torch.sum(alpha, dim=1, keepdim=True)
+    e = alpha - 1
+    m = alpha / s
+    label = F.one_hot(p, num_classes=c)
+    a = torch.sum((label - m) ** 2, dim=1, keepdim=True)
+    b = torch.sum(alpha * (s - alpha) / (s * s * (s + 1)), dim=1, keepdim=True)
+    coef = min(1, global_step / annealing_step)
+    alp = e * (1 - label) + 1
+    return (a + b) + coef * kl_dirichlet(alp, c)
+
+
+# ----------------------------------------------------------------------------
+# TMSU wrapper + sliding window  (models/TrustworthySeg.py:124-166, predict.py:159-191)
+# ----------------------------------------------------------------------------
+
+def tailor_and_concat(x: Tensor, model: Callable[[Tensor], Tensor]) -> Tensor:
+    """predict.py:159-191: eight 128^3 crops, eight disjoint writes, D cut to 155."""
+    lo, hi = slice(0, 128), slice(112, 240)
+    crops = [(lo, lo, slice(0, 128)), (lo, hi, slice(0, 128)), (hi, lo, slice(0, 128)),
+             (hi, hi, slice(0, 128)), (lo, lo, slice(27, 155)), (lo, hi, slice(27, 155)),
+             (hi, lo, slice(27, 155)), (hi, hi, slice(27, 155))]
+    if x.shape[1] == 1:
+        y = torch.cat((x.clone(), x.clone(), x.clone(), x.clone()), 1)
+    elif x.shape[1] == 4:
+        y = x.clone()
+    else:
+        y = torch.cat((x.clone(), x.clone()), 1)
+    outs = [model(x[..., h, w, d]) for (h, w, d) in crops]
+    dst_lo, dst_hi = slice(0, 128), slice(128, 240)
+    src_lo, src_hi = slice(0, 128), slice(16, 128)
+    for i, t in enumerate(outs):
+        hh, ww, dd = (i >> 1) & 1, i & 1, (i >> 2) & 1
+        dst = (dst_hi if hh else dst_lo, dst_hi if ww else dst_lo,
+               slice(128, 155) if dd else slice(0, 128))
+        src = (src_hi if hh else src_lo, src_hi if ww else src_lo,
+               slice(96, 123) if dd else slice(0, 128))
+        y[(Ellipsis,) + dst] = t[(Ellipsis,) + src]
+    return y[..., :155]
+
+
+def tmsu_forward(backbone: Callable[[Tensor], Tensor], x: Tensor, y: Optional[Tensor],
+                 global_step, mode: str, dataset: str, classes: int, lambda_epochs: int,
+                 total_epochs: int, u_loss: bool = False, eps: float = 1e-10):
+    """TMSU.forward, TrustworthySeg.py:124-158.  ``total_epochs`` = end_epochs + 1 (:121)."""
+    if mode != 'train' and dataset == 'BraTS':
+        out = tailor_and_concat(x, backbone)
+    else:
+        out = backbone(x)
+    evidence = F.softplus(out)
+    pred = F.softmax(out, 1)
+    alpha = evidence + 1
+    if mode != 'train':
+        return evidence
+    fn = dce_evidence_u_loss if u_loss else dce_evidence_loss
+    loss = fn(y.to(torch.int64), alpha, classes, global_step, lambda_epochs, total_epochs,
+              eps, False, evidence, pred)
+    return evidence, torch.mean(loss)
+
+
+def infer_head(evidence: Tensor, classes: int):
+    """val/test tensor math: trainUMIS.py:286-290, :446-451; predict.py:92-105."""
+    alpha = evidence + 1
+    s = torch.sum(alpha, dim=1, keepdim=True)
+    prob = alpha / s
+    _, predicted = torch.max(prob, 1)
+    u = classes / s
+    logp = torch.log(prob)
+    mne = torch.sum((-prob * logp / math.log(classes))[:, 1:], dim=1)
+    return predicted, u, prob, mne
+
+
+UNCERTAINTY_THRESHOLDS = [0.05, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95]  # trainUMIS.py:521
+
+
+def poly_lr(init_lr: float, epoch: int, max_epoch: int, power: float = 0.9) -> float:
+    """adjust_learning_rate, trainUMIS.py:217-219."""
+    import numpy as np
+    return round(init_lr * np.power(1 - epoch / max_epoch, power), 8)
