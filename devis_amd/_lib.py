@@ -1,0 +1,108 @@
+"""ctypes binding of libdevis_hip.so (include/devis_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a call
+returns a negative status, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdevis_hip.so")
+
+DEVIS_F32, DEVIS_BF16 = 0, 1
+LABEL_I64, LABEL_U8, LABEL_I32 = 0, 1, 2
+EVID_MAX_K = 8
+EVID_SCAL_FLOATS = 4 + 3 * EVID_MAX_K
+
+_STATUS = {-1: "bad argument", -2: "unsupported shape", -3: "HIP error", -4: "workspace too small"}
+
+
+class DevisError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("N", C.c_int64),
+                ("ID", C.c_int64), ("IH", C.c_int64), ("IW", C.c_int64),
+                ("OD", C.c_int64), ("OH", C.c_int64), ("OW", C.c_int64),
+                ("C1", C.c_int64), ("C2", C.c_int64), ("Cout", C.c_int64),
+                ("KD", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
+                ("SD", C.c_int32), ("SH", C.c_int32), ("SW", C.c_int32),
+                ("PD", C.c_int32), ("PH", C.c_int32), ("PW", C.c_int32),
+                ("dtype", C.c_int32)]
+
+
+class ConvTDesc(C.Structure):
+    _fields_ = [("N", C.c_int64), ("ID", C.c_int64), ("IH", C.c_int64), ("IW", C.c_int64),
+                ("Cin", C.c_int64), ("Cout", C.c_int64),
+                ("KD", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("dtype", C.c_int32)]
+
+
+_P, _I64, _I, _F, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+_CD, _CTD = C.POINTER(ConvDesc), C.POINTER(ConvTDesc)
+
+# name -> (restype, argtypes); every symbol include/devis_hip.h declares
+SIGNATURES = {
+    "devis_version": (_I, []),
+    "devis_last_hip_error": (_I, []),
+    "devis_last_hip_error_string": (C.c_char_p, []),
+    "devis_ncx_to_nxc": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
+    "devis_nxc_to_ncx": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
+    "devis_pack_conv_weight": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
+    "devis_pack_convT_weight": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
+    "devis_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "devis_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _P]),
+    "devis_conv_wgrad_workspace_bytes": (_SZ, [_CD]),
+    "devis_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "devis_convT_fwd": (_I, [_CTD, _P, _P, _P, _P, _P]),
+    "devis_convT_dgrad": (_I, [_CTD, _P, _P, _P, _P]),
+    "devis_convT_wgrad_workspace_bytes": (_SZ, [_CTD]),
+    "devis_convT_wgrad": (_I, [_CTD, _P, _P, _P, _P, _P, _SZ, _P]),
+    "devis_moments_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "devis_channel_moments": (_I, [_P, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
+    "devis_gn_finalize": (_I, [_P, _I64, _I64, _I64, _I64, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "devis_bn_finalize": (_I, [_P, _I64, _I64, _I64, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "devis_affine_act": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P]),
+    "devis_norm_bwd_moments": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
+    "devis_norm_bwd_finalize": (_I, [_P, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "devis_norm_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P]),
+    "devis_add": (_I, [_P, _P, _P, _I64, _I, _P]),
+    "devis_maxpool2d_fwd": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),
+    "devis_maxpool2d_bwd": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),
+    "devis_evid_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "devis_evid_loss_fwd": (_I, [_P, _I64, _I64, _I64, _I, _P, _I, _I64, _I64, _I64, _F, _P, _P, _P, _P, _SZ, _P]),
+    "devis_evid_loss_bwd": (_I, [_P, _I64, _I64, _I64, _I, _P, _I, _I64, _I64, _I64, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "devis_evid_infer": (_I, [_P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "devis_softplus_bwd": (_I, [_P, _P, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DevisError(
+            "libdevis_hip.so not found at %s - build it with devis_amd/csrc/build.sh "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        msg = _STATUS.get(rc, "status %d" % rc)
+        if rc == -3:
+            msg += ": " + lib.devis_last_hip_error_string().decode()
+        raise DevisError("%s failed: %s" % (what, msg))

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libdevis_hip.so in-tree for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+mkdir -p build
+pids=()
+for f in layout conv_direct conv_mfma norm evid capi; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/devis_hip.h -nt build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libdevis_hip.so
+echo "built $(realpath ../libdevis_hip.so)"

@@ -1,0 +1,75 @@
+// C-ABI entry points for convolution: validate, then route to the MFMA implicit-GEMM
+// kernels (conv_mfma.hip) when they take the shape, else to the direct kernels.
+#include "common.h"
+
+namespace devis {
+// conv_direct.hip
+int conv_fwd_direct(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
+                    const float*, const void*, void*, hipStream_t);
+int conv_dgrad_direct(const devis_conv_desc*, const void*, const void*, void*, void*, hipStream_t);
+int conv_wgrad_direct(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
+                      float*, float*, hipStream_t);
+// conv_mfma.hip: return DEVIS_ERR_UNSUPPORTED when the shape is not theirs
+int conv_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
+                  const float*, const void*, void*, hipStream_t);
+int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, void*, void*, hipStream_t);
+size_t conv_wgrad_mfma_workspace(const devis_conv_desc*);
+int conv_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
+                    float*, float*, void*, size_t, hipStream_t);
+
+static bool conv_desc_ok(const devis_conv_desc* d) {
+  if (!d) return false;
+  if (d->N <= 0 || d->ID <= 0 || d->IH <= 0 || d->IW <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0) return false;
+  if (d->KD <= 0 || d->KH <= 0 || d->KW <= 0 || d->SD <= 0 || d->SH <= 0 || d->SW <= 0) return false;
+  if (d->PD < 0 || d->PH < 0 || d->PW < 0) return false;
+  if (d->dtype != DEVIS_F32 && d->dtype != DEVIS_BF16) return false;
+  // the output size must be what the reference's conv produces for this input
+  if (d->OD != (d->ID + 2 * d->PD - d->KD) / d->SD + 1) return false;
+  if (d->OH != (d->IH + 2 * d->PH - d->KH) / d->SH + 1) return false;
+  if (d->OW != (d->IW + 2 * d->PW - d->KW) / d->SW + 1) return false;
+  return d->OD > 0 && d->OH > 0 && d->OW > 0;
+}
+}  // namespace devis
+
+using namespace devis;
+
+extern "C" {
+
+int devis_conv_fwd(const devis_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                   const float* in_scale, const float* in_shift, const void* residual, void* y, void* stream) {
+  if (!conv_desc_ok(d) || !x1 || !w || !y) return DEVIS_ERR_BAD_ARG;
+  if ((d->C2 > 0) != (x2 != nullptr)) return DEVIS_ERR_BAD_ARG;
+  if ((in_scale != nullptr) != (in_shift != nullptr)) return DEVIS_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = conv_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  return conv_fwd_direct(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
+}
+
+int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, void* dx1, void* dx2, void* stream) {
+  if (!conv_desc_ok(d) || !dy || !w || !dx1) return DEVIS_ERR_BAD_ARG;
+  if ((d->C2 > 0) != (dx2 != nullptr)) return DEVIS_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = conv_dgrad_mfma(d, dy, w, dx1, dx2, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  return conv_dgrad_direct(d, dy, w, dx1, dx2, s);
+}
+
+size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d) {
+  if (!conv_desc_ok(d)) return 0;
+  return conv_wgrad_mfma_workspace(d);
+}
+
+int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, const float* in_scale,
+                     const float* in_shift, const void* dy, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                     void* stream) {
+  if (!conv_desc_ok(d) || !x1 || !dy || !dw) return DEVIS_ERR_BAD_ARG;
+  if ((d->C2 > 0) != (x2 != nullptr)) return DEVIS_ERR_BAD_ARG;
+  if ((in_scale != nullptr) != (in_shift != nullptr)) return DEVIS_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = conv_wgrad_mfma(d, x1, x2, in_scale, in_shift, dy, dw, dbias, ws, ws_bytes, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  return conv_wgrad_direct(d, x1, x2, in_scale, in_shift, dy, dw, dbias, s);
+}
+
+}  // extern "C"

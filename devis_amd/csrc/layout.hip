@@ -1,0 +1,81 @@
+// Layout conversion between the reference's NC(D)HW fp32 tensors and the
+// channels-last tensors the kernels work on; weight packing.
+#include "common.h"
+
+namespace devis {
+
+thread_local int g_last_hip_error = 0;
+
+template <typename T>
+__global__ void k_ncx_to_nxc(const float* __restrict__ src, T* __restrict__ dst, int64_t C, int64_t V) {
+  const int64_t n = blockIdx.y;
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const float* s = src + n * C * V + v;
+  T* d = dst + (n * V + v) * C;
+  for (int64_t c = 0; c < C; ++c) st(d + c, s[c * V]);
+}
+
+template <typename T>
+__global__ void k_nxc_to_ncx(const T* __restrict__ src, float* __restrict__ dst, int64_t C, int64_t V) {
+  const int64_t n = blockIdx.y;
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const T* s = src + (n * V + v) * C;
+  float* d = dst + n * C * V + v;
+  for (int64_t c = 0; c < C; ++c) d[c * V] = ld(s + c);
+}
+
+// dst[a][t][b] = src[a][b][t]
+template <typename T>
+__global__ void k_pack_abt(const float* __restrict__ src, T* __restrict__ dst, int64_t A, int64_t B, int64_t Tn) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A * B * Tn) return;
+  const int64_t b = i % B, t = (i / B) % Tn, a = i / (B * Tn);
+  st(dst + i, src[(a * B + b) * Tn + t]);
+}
+// dst[t][co][ci] = src[ci][co][t]
+template <typename T>
+__global__ void k_pack_convT(const float* __restrict__ src, T* __restrict__ dst, int64_t Cin, int64_t Cout, int64_t Tn) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cin * Cout * Tn) return;
+  const int64_t ci = i % Cin, co = (i / Cin) % Cout, t = i / (Cin * Cout);
+  st(dst + i, src[(ci * Cout + co) * Tn + t]);
+}
+
+}  // namespace devis
+
+using namespace devis;
+
+extern "C" {
+
+int devis_version(void) { return 100; }
+int devis_last_hip_error(void) { return g_last_hip_error; }
+const char* devis_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_last_hip_error); }
+
+int devis_ncx_to_nxc(const float* src, void* dst, int64_t N, int64_t C, int64_t V, int dtype, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || V <= 0 || N > 65535) return DEVIS_ERR_BAD_ARG;
+  dim3 grid((unsigned)cdiv(V, 256), (unsigned)N);
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_ncx_to_nxc<T>, grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst, C, V));
+  return launch_status();
+}
+int devis_nxc_to_ncx(const void* src, float* dst, int64_t N, int64_t C, int64_t V, int dtype, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || V <= 0 || N > 65535) return DEVIS_ERR_BAD_ARG;
+  dim3 grid((unsigned)cdiv(V, 256), (unsigned)N);
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_nxc_to_ncx<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, dst, C, V));
+  return launch_status();
+}
+int devis_pack_conv_weight(const float* w, void* dst, int64_t Cout, int64_t Cin, int64_t Tn, int dtype, void* stream) {
+  if (!w || !dst || Cout <= 0 || Cin <= 0 || Tn <= 0) return DEVIS_ERR_BAD_ARG;
+  const int64_t n = Cout * Cin * Tn;
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_abt<T>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (T*)dst, Cout, Cin, Tn));
+  return launch_status();
+}
+int devis_pack_convT_weight(const float* w, void* dst, int64_t Cin, int64_t Cout, int64_t Tn, int dtype, void* stream) {
+  if (!w || !dst || Cout <= 0 || Cin <= 0 || Tn <= 0) return DEVIS_ERR_BAD_ARG;
+  const int64_t n = Cout * Cin * Tn;
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_convT<T>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (T*)dst, Cin, Cout, Tn));
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,453 @@
+// GroupNorm / BatchNorm as "per-(n,c) moments -> per-(n,c) affine": one HBM-bound
+// reduction pass (fp64 accumulation, deterministic two-stage), a tiny finalize, and
+// an elementwise apply that is normally fused into the consuming conv's prologue.
+// Also: residual add, MaxPool2d.
+#include "common.h"
+
+namespace devis {
+
+#define MOM_ROWS 4096  // rows (voxels) per block in the moments kernels
+
+template <typename T> struct Vec;
+template <> struct Vec<float> { static constexpr int N = 4; typedef float4 raw; };
+template <> struct Vec<bf16> { static constexpr int N = 8; typedef uint4 raw; };
+
+template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* out);
+template <> __device__ __forceinline__ void load_vec<float>(const float* p, float* out) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <> __device__ __forceinline__ void load_vec<bf16>(const bf16* p, float* out) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(w[i] << 16);
+    out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* in);
+template <> __device__ __forceinline__ void store_vec<float>(float* p, const float* in) {
+  *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
+}
+template <> __device__ __forceinline__ void store_vec<bf16>(bf16* p, const float* in) {
+  union { bf16 h[8]; uint4 v; } u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) u.h[i] = (bf16)in[i];
+  *reinterpret_cast<uint4*>(p) = u.v;
+}
+
+// MODE 0: {sum x, sum x^2};  MODE 1: dy' = dy*[sc*x+sh>0] -> {sum dy', sum dy'*x}
+// grid = (chunks, N); partial[n][chunk][C][2]
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256)
+k_moments(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ sc,
+          const float* __restrict__ sh, int64_t V, int64_t C, double* __restrict__ partial) {
+  constexpr int VN = Vec<T>::N;
+  __shared__ double red[256 * 2 * VN];
+  const int64_t n = blockIdx.y;
+  const int lanes_per_row = (int)(C / VN);          // host: 256 % lanes_per_row == 0 or lanes_per_row % 256 == 0
+  const int64_t r0 = (int64_t)blockIdx.x * MOM_ROWS;
+  const int64_t r1 = r0 + MOM_ROWS < V ? r0 + MOM_ROWS : V;
+  double* pout = partial + ((n * gridDim.x + blockIdx.x) * C) * 2;
+  for (int cbase = 0; cbase < lanes_per_row; cbase += 256) {
+    const int lpr = lanes_per_row < 256 ? lanes_per_row : 256;
+    const int lane = threadIdx.x % lpr;
+    const int sub = threadIdx.x / lpr;
+    const int nsub = 256 / lpr;
+    const int64_t c0 = (int64_t)(cbase + lane) * VN;
+    double s0[VN], s1[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
+    float scv[VN], shv[VN];
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) { scv[j] = sc[n * C + c0 + j]; shv[j] = sh[n * C + c0 + j]; }
+    }
+    for (int64_t r = r0 + sub; r < r1; r += nsub) {
+      float xv[VN];
+      load_vec<T>(x + (n * V + r) * C + c0, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { const double d = (double)xv[j]; s0[j] += d; s1[j] = fma(d, d, s1[j]); }
+      } else {
+        float gv[VN];
+        load_vec<T>(dy + (n * V + r) * C + c0, gv);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          const float g = fmaf(xv[j], scv[j], shv[j]) > 0.f ? gv[j] : 0.f;
+          s0[j] += (double)g;
+          s1[j] = fma((double)g, (double)xv[j], s1[j]);
+        }
+      }
+    }
+    // combine the nsub sub-rows that share a channel group (fixed order -> deterministic)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      red[(threadIdx.x * VN + j) * 2 + 0] = s0[j];
+      red[(threadIdx.x * VN + j) * 2 + 1] = s1[j];
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        double a = 0.0, b = 0.0;
+        for (int s = 0; s < nsub; ++s) {
+          a += red[((s * lpr + lane) * VN + j) * 2 + 0];
+          b += red[((s * lpr + lane) * VN + j) * 2 + 1];
+        }
+        pout[(c0 + j) * 2 + 0] = a;
+        pout[(c0 + j) * 2 + 1] = b;
+      }
+    }
+  }
+}
+
+// out[n][c][j] = sum_chunk partial[n][chunk][c][j]
+__global__ void k_moments_final(const double* __restrict__ partial, int64_t chunks, int64_t C, int64_t total, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over N*C*2
+  if (i >= total) return;
+  const int64_t n = i / (C * 2), rem = i % (C * 2);
+  const double* p = partial + n * chunks * C * 2 + rem;
+  double a = 0.0;
+  for (int64_t k = 0; k < chunks; ++k) a += p[k * C * 2];
+  out[i] = a;
+}
+
+__global__ void k_gn_finalize(const double* __restrict__ mom, int64_t N, int64_t V, int64_t C, int64_t G,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                              float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
+                              float* __restrict__ rstd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over N*G
+  if (i >= N * G) return;
+  const int64_t n = i / G, g = i % G, cpg = C / G;
+  double s = 0.0, ss = 0.0;
+  for (int64_t c = g * cpg; c < (g + 1) * cpg; ++c) { s += mom[(n * C + c) * 2]; ss += mom[(n * C + c) * 2 + 1]; }
+  const double M = (double)cpg * (double)V;
+  const double mu = s / M;
+  double var = ss / M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float r = 1.0f / sqrtf((float)var + eps);
+  mean[i] = (float)mu;
+  rstd[i] = r;
+  for (int64_t c = g * cpg; c < (g + 1) * cpg; ++c) {
+    const float a = gamma[c] * r;
+    scale[n * C + c] = a;
+    shift[n * C + c] = beta[c] - (float)mu * a;
+  }
+}
+
+__global__ void k_bn_finalize(const double* __restrict__ mom, int64_t N, int64_t V, int64_t C,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                              float momentum, int training, float* __restrict__ rmean, float* __restrict__ rvar,
+                              float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
+                              float* __restrict__ rstd) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mu, r;
+  if (training) {
+    double s = 0.0, ss = 0.0;
+    for (int64_t n = 0; n < N; ++n) { s += mom[(n * C + c) * 2]; ss += mom[(n * C + c) * 2 + 1]; }
+    const double M = (double)N * (double)V;
+    const double m = s / M;
+    double var = ss / M - m * m;
+    if (var < 0.0) var = 0.0;
+    mu = (float)m;
+    r = 1.0f / sqrtf((float)var + eps);
+    if (rmean) {
+      const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+  } else {
+    mu = rmean[c];
+    r = 1.0f / sqrtf(rvar[c] + eps);
+  }
+  mean[c] = mu;
+  rstd[c] = r;
+  const float a = gamma[c] * r, b = beta[c] - mu * a;
+  for (int64_t n = 0; n < N; ++n) { scale[n * C + c] = a; shift[n * C + c] = b; }
+}
+
+// one thread per channel c; loops over n (and over the group's channels for GN)
+__global__ void k_norm_bwd_finalize(const double* __restrict__ mom, int64_t N, int64_t V, int64_t C, int64_t G, int bn,
+                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, float* __restrict__ cA, float* __restrict__ cB,
+                                    float* __restrict__ cC, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double dg = 0.0, db = 0.0;
+  if (bn) {
+    double m0 = 0.0, m1 = 0.0;
+    for (int64_t n = 0; n < N; ++n) { m0 += mom[(n * C + c) * 2]; m1 += mom[(n * C + c) * 2 + 1]; }
+    const double mu = mean[c], r = rstd[c], gm = gamma[c];
+    const double M = (double)N * (double)V;
+    const double s1 = gm * m0, sxy = gm * m1;
+    const double s2 = r * (sxy - mu * s1);
+    const double B = -r * r * s2 / M;
+    const double Cc = -r * s1 / M - mu * B;
+    for (int64_t n = 0; n < N; ++n) { cA[n * C + c] = (float)(gm * r); cB[n * C + c] = (float)B; cC[n * C + c] = (float)Cc; }
+    dg = r * (m1 - mu * m0);
+    db = m0;
+  } else {
+    const int64_t cpg = C / G, g = c / cpg;
+    const double M = (double)cpg * (double)V;
+    for (int64_t n = 0; n < N; ++n) {
+      double s1 = 0.0, sxy = 0.0;
+      for (int64_t k = g * cpg; k < (g + 1) * cpg; ++k) {
+        s1 += (double)gamma[k] * mom[(n * C + k) * 2];
+        sxy += (double)gamma[k] * mom[(n * C + k) * 2 + 1];
+      }
+      const double mu = mean[n * G + g], r = rstd[n * G + g];
+      const double s2 = r * (sxy - mu * s1);
+      const double B = -r * r * s2 / M;
+      cA[n * C + c] = (float)((double)gamma[c] * r);
+      cB[n * C + c] = (float)B;
+      cC[n * C + c] = (float)(-r * s1 / M - mu * B);
+      const double m0 = mom[(n * C + c) * 2], m1 = mom[(n * C + c) * 2 + 1];
+      dg += r * (m1 - mu * m0);
+      db += m0;
+    }
+  }
+  dgamma[c] = (float)dg;
+  dbeta[c] = (float)db;
+}
+
+// ---------------------------------------------------------------- elementwise
+// one thread per vector of VN channels; flat over N*V*C/VN
+template <typename T, bool RELU, bool RES>
+__global__ void __launch_bounds__(256)
+k_affine_act(const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+             const T* __restrict__ res, T* __restrict__ y, int64_t VC, int64_t C, int64_t nvec) {
+  constexpr int VN = Vec<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * VN;
+    const int64_t n = e / VC, c0 = e % C;
+    float v[VN], r[VN];
+    load_vec<T>(x + e, v);
+    if (RES) load_vec<T>(res + e, r);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      float t = fmaf(v[j], sc[n * C + c0 + j], sh[n * C + c0 + j]);
+      if (RELU) t = fmaxf(t, 0.f);
+      if (RES) t += r[j];
+      v[j] = t;
+    }
+    store_vec<T>(y + e, v);
+  }
+}
+
+template <typename T, bool EXTRA>
+__global__ void __launch_bounds__(256)
+k_norm_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sc,
+                 const float* __restrict__ sh, const float* __restrict__ cA, const float* __restrict__ cB,
+                 const float* __restrict__ cC, const T* __restrict__ extra, T* __restrict__ dx, int64_t VC,
+                 int64_t C, int64_t nvec) {
+  constexpr int VN = Vec<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * VN;
+    const int64_t n = e / VC, c0 = e % C;
+    float g[VN], xv[VN], ex[VN];
+    load_vec<T>(dy + e, g);
+    load_vec<T>(x + e, xv);
+    if (EXTRA) load_vec<T>(extra + e, ex);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      const int64_t k = n * C + c0 + j;
+      const float gm = fmaf(xv[j], sc[k], sh[k]) > 0.f ? g[j] : 0.f;
+      float t = fmaf(cA[k], gm, fmaf(cB[k], xv[j], cC[k]));
+      if (EXTRA) t += ex[j];
+      g[j] = t;
+    }
+    store_vec<T>(dx + e, g);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_add(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ z, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    st(z + i, ld(a + i) + ld(b + i));
+}
+
+// -------------------------------------------------------------------- maxpool
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_maxpool_fwd(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int64_t N, int64_t H, int64_t W, int64_t C) {
+  const int64_t OH = H / 2, OW = W / 2;
+  const int64_t total = N * OH * OW * C;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t c = i % C;
+  int64_t r = i / C;
+  const int64_t ow = r % OW; r /= OW;
+  const int64_t oh = r % OH;
+  const int64_t n = r / OH;
+  float best = 0.f;
+  int bi = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {   // scan order (kh, kw); strictly-greater keeps the first maximum
+    const float v = ld(x + ((n * H + oh * 2 + (k >> 1)) * W + ow * 2 + (k & 1)) * C + c);
+    if (k == 0 || v > best || v != v) { best = v; bi = k; }
+  }
+  st(y + i, best);
+  idx[i] = (uint8_t)bi;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int64_t N, int64_t H, int64_t W, int64_t C) {
+  const int64_t OH = H / 2, OW = W / 2;
+  const int64_t total = N * H * W * C;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t c = i % C;
+  int64_t r = i / C;
+  const int64_t w = r % W; r /= W;
+  const int64_t h = r % H;
+  const int64_t n = r / H;
+  float g = 0.f;
+  const int64_t oh = h / 2, ow = w / 2;
+  if (oh < OH && ow < OW) {
+    const int64_t o = ((n * OH + oh) * OW + ow) * C + c;
+    if (idx[o] == (uint8_t)((h & 1) * 2 + (w & 1))) g = ld(dy + o);
+  }
+  st(dx + i, g);
+}
+
+static inline bool vec_ok(int64_t C, int dtype) {
+  const int vn = dtype == DEVIS_F32 ? 4 : 8;
+  if (C % vn) return false;
+  const int64_t lpr = C / vn;
+  return (256 % lpr == 0) || (lpr % 256 == 0);
+}
+
+static inline unsigned ew_grid(int64_t nvec) {
+  const int64_t b = cdiv(nvec, 256);
+  return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace devis
+
+using namespace devis;
+
+extern "C" {
+
+size_t devis_moments_workspace_bytes(int64_t N, int64_t V, int64_t C) {
+  if (N <= 0 || V <= 0 || C <= 0) return 0;
+  return (size_t)(N * cdiv(V, MOM_ROWS) * C * 2) * sizeof(double);
+}
+
+static int moments_impl(int mode, const void* x, const void* dy, const float* sc, const float* sh, int64_t N,
+                        int64_t V, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !out || !ws || N <= 0 || V <= 0 || C <= 0 || N > 65535) return DEVIS_ERR_BAD_ARG;
+  if (!vec_ok(C, dtype)) return DEVIS_ERR_UNSUPPORTED;
+  if (ws_bytes < devis_moments_workspace_bytes(N, V, C)) return DEVIS_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t chunks = cdiv(V, MOM_ROWS);
+  const dim3 grid((unsigned)chunks, (unsigned)N);
+  DEVIS_DISPATCH_DTYPE(dtype, {
+    if (mode == 0) hipLaunchKernelGGL((k_moments<T, 0>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, sc, sh, V, C, (double*)ws);
+    else hipLaunchKernelGGL((k_moments<T, 1>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, sc, sh, V, C, (double*)ws);
+  });
+  int rc = launch_status();
+  if (rc) return rc;
+  const int64_t total = N * C * 2;
+  hipLaunchKernelGGL(k_moments_final, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const double*)ws, chunks, C, total, out);
+  return launch_status();
+}
+
+int devis_channel_moments(const void* x, int64_t N, int64_t V, int64_t C, int dtype, double* out, void* ws,
+                          size_t ws_bytes, void* stream) {
+  return moments_impl(0, x, nullptr, nullptr, nullptr, N, V, C, dtype, out, ws, ws_bytes, stream);
+}
+
+int devis_norm_bwd_moments(const void* dy, const void* x, const float* sc, const float* sh, int64_t N, int64_t V,
+                           int64_t C, int dtype, double* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !sc || !sh) return DEVIS_ERR_BAD_ARG;
+  return moments_impl(1, x, dy, sc, sh, N, V, C, dtype, out, ws, ws_bytes, stream);
+}
+
+int devis_gn_finalize(const double* mom, int64_t N, int64_t V, int64_t C, int64_t G, const float* gamma,
+                      const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd, void* stream) {
+  if (!mom || !gamma || !beta || !scale || !shift || !mean || !rstd || N <= 0 || V <= 0 || G <= 0 || C % G) return DEVIS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)cdiv(N * G, 64)), dim3(64), 0, (hipStream_t)stream, mom, N, V, C, G, gamma, beta, eps, scale, shift, mean, rstd);
+  return launch_status();
+}
+
+int devis_bn_finalize(const double* mom, int64_t N, int64_t V, int64_t C, const float* gamma, const float* beta,
+                      float eps, float momentum, int training, float* rmean, float* rvar, float* scale, float* shift,
+                      float* mean, float* rstd, void* stream) {
+  if (!gamma || !beta || !scale || !shift || !mean || !rstd || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
+  if (training && !mom) return DEVIS_ERR_BAD_ARG;
+  if (!training && (!rmean || !rvar)) return DEVIS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, mom, N, V, C, gamma, beta, eps, momentum, training, rmean, rvar, scale, shift, mean, rstd);
+  return launch_status();
+}
+
+int devis_norm_bwd_finalize(const double* mom, int64_t N, int64_t V, int64_t C, int64_t G, int bn, const float* gamma,
+                            const float* mean, const float* rstd, float* cA, float* cB, float* cC, float* dgamma,
+                            float* dbeta, void* stream) {
+  if (!mom || !gamma || !mean || !rstd || !cA || !cB || !cC || !dgamma || !dbeta || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
+  if (!bn && (G <= 0 || C % G)) return DEVIS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, mom, N, V, C, G, bn, gamma, mean, rstd, cA, cB, cC, dgamma, dbeta);
+  return launch_status();
+}
+
+int devis_affine_act(const void* x, const float* sc, const float* sh, const void* res, void* y, int64_t N, int64_t V,
+                     int64_t C, int dtype, int relu, void* stream) {
+  if (!x || !sc || !sh || !y || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
+  const int vn = dtype == DEVIS_F32 ? 4 : 8;
+  if (C % vn) return DEVIS_ERR_UNSUPPORTED;
+  const int64_t nvec = N * V * C / vn;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(ew_grid(nvec));
+#define LAUNCH_AA(R, S) hipLaunchKernelGGL((k_affine_act<T, R, S>), grid, dim3(256), 0, s, (const T*)x, sc, sh, (const T*)res, (T*)y, V * C, C, nvec)
+  DEVIS_DISPATCH_DTYPE(dtype, {
+    if (relu && res) LAUNCH_AA(true, true);
+    else if (relu) LAUNCH_AA(true, false);
+    else if (res) LAUNCH_AA(false, true);
+    else LAUNCH_AA(false, false);
+  });
+#undef LAUNCH_AA
+  return launch_status();
+}
+
+int devis_norm_bwd_apply(const void* dy, const void* x, const float* sc, const float* sh, const float* cA,
+                         const float* cB, const float* cC, const void* extra, void* dx, int64_t N, int64_t V,
+                         int64_t C, int dtype, void* stream) {
+  if (!dy || !x || !sc || !sh || !cA || !cB || !cC || !dx || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
+  const int vn = dtype == DEVIS_F32 ? 4 : 8;
+  if (C % vn) return DEVIS_ERR_UNSUPPORTED;
+  const int64_t nvec = N * V * C / vn;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(ew_grid(nvec));
+  DEVIS_DISPATCH_DTYPE(dtype, {
+    if (extra) hipLaunchKernelGGL((k_norm_bwd_apply<T, true>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, sc, sh, cA, cB, cC, (const T*)extra, (T*)dx, V * C, C, nvec);
+    else hipLaunchKernelGGL((k_norm_bwd_apply<T, false>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, sc, sh, cA, cB, cC, (const T*)extra, (T*)dx, V * C, C, nvec);
+  });
+  return launch_status();
+}
+
+int devis_add(const void* a, const void* b, void* z, int64_t n, int dtype, void* stream) {
+  if (!a || !b || !z || n <= 0) return DEVIS_ERR_BAD_ARG;
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_add<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)z, n));
+  return launch_status();
+}
+
+int devis_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int64_t N, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+  if (!x || !y || !idx || N <= 0 || H < 2 || W < 2 || C <= 0) return DEVIS_ERR_BAD_ARG;
+  const int64_t total = N * (H / 2) * (W / 2) * C;
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_maxpool_fwd<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, idx, N, H, W, C));
+  return launch_status();
+}
+
+int devis_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int64_t N, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+  if (!dy || !dx || !idx || N <= 0 || H < 2 || W < 2 || C <= 0) return DEVIS_ERR_BAD_ARG;
+  const int64_t total = N * H * W * C;
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, idx, (T*)dx, N, H, W, C));
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,426 @@
+"""Thin, shape-checked wrappers: torch tensors in/out, HIP kernels underneath.
+
+Activations are channels-last tensors ``[N, D, H, W, C]`` (3-D) or ``[N, H, W, C]``
+(2-D), dtype float32 or bfloat16.  torch is used for memory (``torch.empty``) and the
+current stream only; every computation is a libdevis_hip.so call.  None of these
+functions is differentiable by autograd - the manual backward lives in
+``devis_amd/unet3d.py`` / ``unet2d.py`` / ``criterions.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, ConvTDesc, check
+
+Tensor = torch.Tensor
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return _lib.DEVIS_F32
+    if dtype == torch.bfloat16:
+        return _lib.DEVIS_BF16
+    raise _lib.DevisError("unsupported compute dtype %s (float32 or bfloat16)" % dtype)
+
+
+def _need_cuda(*ts: Optional[Tensor]) -> None:
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise _lib.DevisError("devis_amd kernels need GPU tensors (got a %s tensor); "
+                                      "there is no CPU fallback" % t.device)
+            if not t.is_contiguous():
+                raise _lib.DevisError("devis_amd kernels need contiguous tensors")
+
+
+def _spatial(x: Tensor) -> Tuple[int, int, int]:
+    if x.dim() == 5:
+        return x.shape[1], x.shape[2], x.shape[3]
+    if x.dim() == 4:
+        return 1, x.shape[1], x.shape[2]
+    raise _lib.DevisError("expected a channels-last 4-D or 5-D tensor, got %d-D" % x.dim())
+
+
+_ws = {}
+
+
+def workspace(nbytes: int, device: torch.device, slot: str = "ws") -> Tensor:
+    """Per-device scratch that only ever grows (the library itself never allocates)."""
+    key = (device.index, slot)
+    t = _ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = t
+    return t
+
+
+# ------------------------------------------------------------------ layout
+def to_channels_last(x: Tensor, dtype: torch.dtype) -> Tensor:
+    """NC(D)HW fp32 -> channels-last `dtype`."""
+    x = x.contiguous().float()
+    _need_cuda(x)
+    n, c = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:])
+    v = 1
+    for s in sp:
+        v *= s
+    y = torch.empty((n,) + sp + (c,), dtype=dtype, device=x.device)
+    check(_lib.load().devis_ncx_to_nxc(_p(x), _p(y), n, c, v, dt_code(dtype), _stream()), "ncx_to_nxc")
+    return y
+
+
+def from_channels_last(y: Tensor) -> Tensor:
+    """channels-last -> NC(D)HW fp32."""
+    _need_cuda(y)
+    n, c = y.shape[0], y.shape[-1]
+    sp = tuple(y.shape[1:-1])
+    v = 1
+    for s in sp:
+        v *= s
+    x = torch.empty((n, c) + sp, dtype=torch.float32, device=y.device)
+    check(_lib.load().devis_nxc_to_ncx(_p(y), _p(x), n, c, v, dt_code(y.dtype), _stream()), "nxc_to_ncx")
+    return x
+
+
+def pack_conv_weight(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """[Cout, Cin, *k] fp32 -> [Cout, T, Cin] `dtype`."""
+    w = w.detach().contiguous()
+    _need_cuda(w)
+    co, ci = w.shape[0], w.shape[1]
+    t = w.numel() // (co * ci)
+    out = torch.empty((co, t, ci), dtype=dtype, device=w.device)
+    check(_lib.load().devis_pack_conv_weight(_p(w), _p(out), co, ci, t, dt_code(dtype), _stream()), "pack_conv_weight")
+    return out
+
+
+def pack_convT_weight(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """[Cin, Cout, *k] fp32 -> [T, Cout, Cin] `dtype`."""
+    w = w.detach().contiguous()
+    _need_cuda(w)
+    ci, co = w.shape[0], w.shape[1]
+    t = w.numel() // (co * ci)
+    out = torch.empty((t, co, ci), dtype=dtype, device=w.device)
+    check(_lib.load().devis_pack_convT_weight(_p(w), _p(out), ci, co, t, dt_code(dtype), _stream()), "pack_convT_weight")
+    return out
+
+
+# -------------------------------------------------------------------- conv
+class ConvGeom:
+    """kernel / stride / padding of one conv layer, each a (d, h, w) triple."""
+
+    def __init__(self, kernel: Sequence[int], stride: Sequence[int], pad: Sequence[int]):
+        def tri(v):
+            v = tuple(int(a) for a in v)
+            return (1,) * (3 - len(v)) + v if len(v) < 3 else v
+        self.k, self.s = tri(kernel), tri(stride)
+        p = tuple(int(a) for a in pad)
+        self.p = (0,) * (3 - len(p)) + p if len(p) < 3 else p
+
+    def out_spatial(self, isp: Tuple[int, int, int]) -> Tuple[int, int, int]:
+        return tuple((i + 2 * p - k) // s + 1 for i, k, s, p in zip(isp, self.k, self.s, self.p))
+
+    def desc(self, n: int, isp, c1: int, c2: int, cout: int, dtype: torch.dtype) -> ConvDesc:
+        osp = self.out_spatial(isp)
+        return ConvDesc(n, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2], c1, c2, cout,
+                        self.k[0], self.k[1], self.k[2], self.s[0], self.s[1], self.s[2],
+                        self.p[0], self.p[1], self.p[2], dt_code(dtype))
+
+
+def _out_shape(x: Tensor, osp, cout: int):
+    return (x.shape[0],) + (tuple(osp) if x.dim() == 5 else tuple(osp[1:])) + (cout,)
+
+
+def conv_fwd(x1: Tensor, x2: Optional[Tensor], wp: Tensor, bias: Optional[Tensor], geom: ConvGeom,
+             scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+             residual: Optional[Tensor] = None) -> Tensor:
+    _need_cuda(x1, x2, wp, bias, scale, shift, residual)
+    isp = _spatial(x1)
+    c1 = x1.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    cout = wp.shape[0]
+    if wp.shape[2] != c1 + c2 or wp.shape[1] != geom.k[0] * geom.k[1] * geom.k[2]:
+        raise _lib.DevisError("packed weight %s does not match input channels %d+%d / kernel %s"
+                              % (tuple(wp.shape), c1, c2, geom.k))
+    if x2 is not None and x2.shape[:-1] != x1.shape[:-1]:
+        raise _lib.DevisError("virtual-concat inputs differ in shape")
+    if wp.dtype != x1.dtype:
+        raise _lib.DevisError("weight dtype %s != activation dtype %s" % (wp.dtype, x1.dtype))
+    d = geom.desc(x1.shape[0], isp, c1, c2, cout, x1.dtype)
+    y = torch.empty(_out_shape(x1, (d.OD, d.OH, d.OW), cout), dtype=x1.dtype, device=x1.device)
+    if residual is not None and residual.shape != y.shape:
+        raise _lib.DevisError("residual shape mismatch")
+    if scale is not None and scale.numel() != x1.shape[0] * (c1 + c2):
+        raise _lib.DevisError("prologue scale must be [N, Cin]")
+    check(_lib.load().devis_conv_fwd(C.byref(d), _p(x1), _p(x2), _p(wp), _p(bias), _p(scale), _p(shift),
+                                     _p(residual), _p(y), _stream()), "conv_fwd")
+    return y
+
+
+def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0):
+    """-> (dx1, dx2|None): gradient w.r.t. the conv's (post-prologue) inputs."""
+    _need_cuda(dy, wp)
+    n = in_shape1[0]
+    c1 = in_shape1[-1]
+    isp = tuple(in_shape1[1:-1]) if len(in_shape1) == 5 else (1,) + tuple(in_shape1[1:-1])
+    d = geom.desc(n, isp, c1, c2, wp.shape[0], dy.dtype)
+    if _spatial(dy) != (d.OD, d.OH, d.OW) or dy.shape[-1] != wp.shape[0]:
+        raise _lib.DevisError("dgrad: dy shape %s inconsistent with the layer" % (tuple(dy.shape),))
+    dx1 = torch.empty(tuple(in_shape1), dtype=dy.dtype, device=dy.device)
+    dx2 = torch.empty(tuple(in_shape1[:-1]) + (c2,), dtype=dy.dtype, device=dy.device) if c2 else None
+    check(_lib.load().devis_conv_dgrad(C.byref(d), _p(dy), _p(wp), _p(dx1), _p(dx2), _stream()), "conv_dgrad")
+    return dx1, dx2
+
+
+def conv_wgrad(x1: Tensor, x2: Optional[Tensor], dy: Tensor, geom: ConvGeom, wshape,
+               scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, want_bias: bool = True):
+    """-> (dw in the PyTorch layout `wshape` fp32, dbias fp32|None)."""
+    _need_cuda(x1, x2, dy, scale, shift)
+    c1 = x1.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    cout = dy.shape[-1]
+    d = geom.desc(x1.shape[0], _spatial(x1), c1, c2, cout, x1.dtype)
+    if _spatial(dy) != (d.OD, d.OH, d.OW):
+        raise _lib.DevisError("wgrad: dy shape inconsistent with the layer")
+    dw = torch.empty(tuple(wshape), dtype=torch.float32, device=x1.device)
+    if dw.numel() != cout * (c1 + c2) * geom.k[0] * geom.k[1] * geom.k[2]:
+        raise _lib.DevisError("wgrad: weight shape mismatch")
+    db = torch.empty((cout,), dtype=torch.float32, device=x1.device) if want_bias else None
+    lib = _lib.load()
+    nb = lib.devis_conv_wgrad_workspace_bytes(C.byref(d))
+    ws = workspace(nb, x1.device) if nb else None
+    check(lib.devis_conv_wgrad(C.byref(d), _p(x1), _p(x2), _p(scale), _p(shift), _p(dy), _p(dw), _p(db),
+                               _p(ws), nb, _stream()), "conv_wgrad")
+    return dw, db
+
+
+def _tdesc(x_shape, cin: int, cout: int, k, dtype) -> ConvTDesc:
+    isp = tuple(x_shape[1:-1]) if len(x_shape) == 5 else (1,) + tuple(x_shape[1:-1])
+    k = tuple(k)
+    k = (1,) * (3 - len(k)) + k
+    return ConvTDesc(x_shape[0], isp[0], isp[1], isp[2], cin, cout, k[0], k[1], k[2], dt_code(dtype))
+
+
+def convT_fwd(x: Tensor, wp: Tensor, bias: Optional[Tensor], k) -> Tensor:
+    _need_cuda(x, wp, bias)
+    cout, cin = wp.shape[1], wp.shape[2]
+    if cin != x.shape[-1]:
+        raise _lib.DevisError("convT: channel mismatch")
+    d = _tdesc(x.shape, cin, cout, k, x.dtype)
+    osp = (d.ID * d.KD, d.IH * d.KH, d.IW * d.KW)
+    y = torch.empty(_out_shape(x, osp, cout), dtype=x.dtype, device=x.device)
+    check(_lib.load().devis_convT_fwd(C.byref(d), _p(x), _p(wp), _p(bias), _p(y), _stream()), "convT_fwd")
+    return y
+
+
+def convT_dgrad(dy: Tensor, wp: Tensor, k, x_shape) -> Tensor:
+    _need_cuda(dy, wp)
+    d = _tdesc(x_shape, wp.shape[2], wp.shape[1], k, dy.dtype)
+    dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
+    check(_lib.load().devis_convT_dgrad(C.byref(d), _p(dy), _p(wp), _p(dx), _stream()), "convT_dgrad")
+    return dx
+
+
+def convT_wgrad(x: Tensor, dy: Tensor, k, wshape):
+    _need_cuda(x, dy)
+    cin, cout = wshape[0], wshape[1]
+    d = _tdesc(x.shape, cin, cout, k, x.dtype)
+    dw = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    check(_lib.load().devis_convT_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), None, 0, _stream()), "convT_wgrad")
+    return dw, db
+
+
+# -------------------------------------------------------------------- norm
+def _nvc(x: Tensor):
+    n, c = x.shape[0], x.shape[-1]
+    return n, x.numel() // (n * c), c
+
+
+def _moments(x: Tensor, dy: Optional[Tensor] = None, scale=None, shift=None) -> Tensor:
+    n, v, c = _nvc(x)
+    lib = _lib.load()
+    nb = lib.devis_moments_workspace_bytes(n, v, c)
+    ws = workspace(nb, x.device)
+    out = torch.empty((n, c, 2), dtype=torch.float64, device=x.device)
+    if dy is None:
+        check(lib.devis_channel_moments(_p(x), n, v, c, dt_code(x.dtype), _p(out), _p(ws), nb, _stream()), "channel_moments")
+    else:
+        check(lib.devis_norm_bwd_moments(_p(dy), _p(x), _p(scale), _p(shift), n, v, c, dt_code(x.dtype), _p(out),
+                                         _p(ws), nb, _stream()), "norm_bwd_moments")
+    return out
+
+
+def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 8, eps: float = 1e-5):
+    """GroupNorm statistics -> (scale[N,C], shift[N,C], mean[N,G], rstd[N,G])."""
+    _need_cuda(x, gamma, beta)
+    n, v, c = _nvc(x)
+    mom = _moments(x)
+    f = dict(dtype=torch.float32, device=x.device)
+    scale, shift = torch.empty((n, c), **f), torch.empty((n, c), **f)
+    mean, rstd = torch.empty((n, groups), **f), torch.empty((n, groups), **f)
+    check(_lib.load().devis_gn_finalize(_p(mom), n, v, c, groups, _p(gamma), _p(beta), eps, _p(scale), _p(shift),
+                                        _p(mean), _p(rstd), _stream()), "gn_finalize")
+    return scale, shift, mean, rstd
+
+
+def bn_stats(x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor, running_var: Tensor, training: bool,
+             momentum: float = 0.1, eps: float = 1e-5):
+    """BatchNorm coefficients; updates the running buffers in place when training."""
+    _need_cuda(x, gamma, beta, running_mean, running_var)
+    n, v, c = _nvc(x)
+    mom = _moments(x) if training else None
+    f = dict(dtype=torch.float32, device=x.device)
+    scale, shift = torch.empty((n, c), **f), torch.empty((n, c), **f)
+    mean, rstd = torch.empty((c,), **f), torch.empty((c,), **f)
+    check(_lib.load().devis_bn_finalize(_p(mom), n, v, c, _p(gamma), _p(beta), eps, momentum, int(training),
+                                        _p(running_mean), _p(running_var), _p(scale), _p(shift), _p(mean), _p(rstd),
+                                        _stream()), "bn_finalize")
+    return scale, shift, mean, rstd
+
+
+def affine_act(x: Tensor, scale: Tensor, shift: Tensor, residual: Optional[Tensor] = None, relu: bool = True) -> Tensor:
+    _need_cuda(x, scale, shift, residual)
+    n, v, c = _nvc(x)
+    y = torch.empty_like(x)
+    check(_lib.load().devis_affine_act(_p(x), _p(scale), _p(shift), _p(residual), _p(y), n, v, c, dt_code(x.dtype),
+                                       int(relu), _stream()), "affine_act")
+    return y
+
+
+def norm_relu_bwd(dy: Tensor, x: Tensor, scale: Tensor, shift: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
+                  groups: int, bn: bool, extra: Optional[Tensor] = None):
+    """Backward of relu(norm(x)) -> (dx (+extra), dgamma, dbeta)."""
+    _need_cuda(dy, x, extra)
+    n, v, c = _nvc(x)
+    mom = _moments(x, dy, scale, shift)
+    f = dict(dtype=torch.float32, device=x.device)
+    coef = torch.empty((3, n, c), **f)
+    dgamma, dbeta = torch.empty((c,), **f), torch.empty((c,), **f)
+    lib = _lib.load()
+    check(lib.devis_norm_bwd_finalize(_p(mom), n, v, c, groups, int(bn), _p(gamma), _p(mean), _p(rstd),
+                                      _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(dgamma), _p(dbeta), _stream()),
+          "norm_bwd_finalize")
+    dx = torch.empty_like(x)
+    check(lib.devis_norm_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                   _p(extra), _p(dx), n, v, c, dt_code(x.dtype), _stream()), "norm_bwd_apply")
+    return dx, dgamma, dbeta
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    _need_cuda(a, b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise _lib.DevisError("add: shape/dtype mismatch")
+    z = torch.empty_like(a)
+    check(_lib.load().devis_add(_p(a), _p(b), _p(z), a.numel(), dt_code(a.dtype), _stream()), "add")
+    return z
+
+
+def maxpool2d_fwd(x: Tensor):
+    _need_cuda(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device)
+    check(_lib.load().devis_maxpool2d_fwd(_p(x), _p(y), _p(idx), n, h, w, c, dt_code(x.dtype), _stream()), "maxpool_fwd")
+    return y, idx
+
+
+def maxpool2d_bwd(dy: Tensor, idx: Tensor, x_shape) -> Tensor:
+    _need_cuda(dy, idx)
+    n, h, w, c = x_shape
+    dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
+    check(_lib.load().devis_maxpool2d_bwd(_p(dy), _p(idx), _p(dx), n, h, w, c, dt_code(dy.dtype), _stream()), "maxpool_bwd")
+    return dx
+
+
+# ------------------------------------------------------------ evidential
+def _label_code(labels: Tensor) -> int:
+    if labels.dtype == torch.int64:
+        return _lib.LABEL_I64
+    if labels.dtype == torch.uint8:
+        return _lib.LABEL_U8
+    if labels.dtype == torch.int32:
+        return _lib.LABEL_I32
+    raise _lib.DevisError("labels must be int64, int32 or uint8")
+
+
+def logits_strides(logits: Tensor, channels_last: bool):
+    """(N, V, K, sN, sV, sK) in elements for a contiguous logits tensor."""
+    n = logits.shape[0]
+    if channels_last:
+        k = logits.shape[-1]
+        v = logits.numel() // (n * k)
+        return n, v, k, v * k, k, 1
+    k = logits.shape[1]
+    v = logits.numel() // (n * k)
+    return n, v, k, v * k, 1, v
+
+
+def evid_loss_fwd(logits: Tensor, channels_last: bool, labels: Tensor, lam: float, want_evidence: bool,
+                  want_per_voxel: bool = False):
+    _need_cuda(logits, labels)
+    n, v, k, sn, sv, sk = logits_strides(logits, channels_last)
+    if labels.numel() != n * v:
+        raise _lib.DevisError("labels must hold one class index per voxel")
+    f = dict(dtype=torch.float32, device=logits.device)
+    sp = tuple(logits.shape[1:-1]) if channels_last else tuple(logits.shape[2:])
+    evidence = torch.empty((n, k) + sp, **f) if want_evidence else None
+    per_voxel = torch.empty((n * v, 1), **f) if want_per_voxel else None
+    scal = torch.empty((_lib.EVID_SCAL_FLOATS,), **f)
+    lib = _lib.load()
+    nb = lib.devis_evid_workspace_bytes(n, v, k)
+    ws = workspace(nb, logits.device)
+    check(lib.devis_evid_loss_fwd(_p(logits), sn, sv, sk, dt_code(logits.dtype), _p(labels), _label_code(labels),
+                                  n, v, k, float(lam), _p(evidence), _p(per_voxel), _p(scal), _p(ws), nb, _stream()),
+          "evid_loss_fwd")
+    return scal, evidence, per_voxel
+
+
+def evid_loss_bwd(logits: Tensor, channels_last: bool, labels: Tensor, lam: float, scal: Tensor,
+                  grad_loss: Optional[Tensor], grad_evidence: Optional[Tensor] = None,
+                  grad_per_voxel: Optional[Tensor] = None, grad_dice: Optional[Tensor] = None) -> Tensor:
+    _need_cuda(logits, labels, scal, grad_loss, grad_evidence, grad_per_voxel, grad_dice)
+    n, v, k, sn, sv, sk = logits_strides(logits, channels_last)
+    dz = torch.empty_like(logits)
+    check(_lib.load().devis_evid_loss_bwd(_p(logits), sn, sv, sk, dt_code(logits.dtype), _p(labels), _label_code(labels),
+                                          n, v, k, float(lam), _p(scal), _p(grad_loss), _p(grad_per_voxel),
+                                          _p(grad_dice), _p(grad_evidence), _p(dz), _stream()), "evid_loss_bwd")
+    return dz
+
+
+def evid_infer(logits: Tensor, channels_last: bool, thresholds: Sequence[float] = (), want_evidence: bool = True,
+               want_mne: bool = False):
+    """-> dict(evidence, pred uint8, u fp32, mne, umask uint16)."""
+    _need_cuda(logits)
+    n, v, k, sn, sv, sk = logits_strides(logits, channels_last)
+    sp = tuple(logits.shape[1:-1]) if channels_last else tuple(logits.shape[2:])
+    dev = logits.device
+    evidence = torch.empty((n, k) + sp, dtype=torch.float32, device=dev) if want_evidence else None
+    pred = torch.empty((n,) + sp, dtype=torch.uint8, device=dev)
+    u = torch.empty((n, 1) + sp, dtype=torch.float32, device=dev)
+    mne = torch.empty((n,) + sp, dtype=torch.float32, device=dev) if want_mne else None
+    nthr = len(thresholds)
+    umask = torch.empty((n,) + sp, dtype=torch.int16, device=dev) if nthr else None
+    thr = (C.c_float * max(nthr, 1))(*[float(t) for t in thresholds])
+    check(_lib.load().devis_evid_infer(_p(logits), sn, sv, sk, dt_code(logits.dtype), n, v, k, _p(evidence), _p(pred),
+                                       _p(u), _p(mne), _p(umask), C.cast(thr, C.c_void_p), nthr, _stream()),
+          "evid_infer")
+    return dict(evidence=evidence, pred=pred, u=u, mne=mne, umask=umask)
+
+
+def softplus_bwd(z: Tensor, g: Tensor) -> Tensor:
+    _need_cuda(z, g)
+    dz = torch.empty_like(z)
+    check(_lib.load().devis_softplus_bwd(_p(z), _p(g), _p(dz), z.numel(), _stream()), "softplus_bwd")
+    return dz

@@ -1,0 +1,107 @@
+"""TMSU: the evidential segmentation wrapper (reference models/TrustworthySeg.py:21-166).
+
+Same constructor argument (`args` namespace), attributes and ``forward(X, y, global_step,
+mode, dataset)`` / ``infer(input)`` behaviour; the backbone and the head+loss are the HIP
+kernels of this package.  Deviations from the reference, all documented in DESIGN.md:
+  * ``self.backbone.cuda()`` (TrustworthySeg.py:116) becomes ``.to(current cuda device)``;
+  * the ISIC branch, which raises NameError in the reference (TrustworthySeg.py:51 uses the
+    undefined names ``model``/``classes``), selects ``Unet2D(3, num_classes)`` for model 'U';
+  * backbones outside SURVEY.md §8 (AU, V, ResU) raise NameError like an unknown model does.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .criterions import evidential_head_loss, dce_evidence_u_loss
+from .predict import tailor_and_concat
+from .unet2d import Unet2D, Unet2DDRIVE
+from .unet3d import Unet
+
+
+class TMSU(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        num_classes = args.num_classes
+        dataset = args.dataset
+        model_name = args.model_name
+        input_modality = args.input_modality
+        dtype = getattr(args, "compute_dtype", torch.bfloat16)
+        backbone = None
+        if dataset == 'BraTS':
+            if model_name == 'U' and input_modality == 'four':
+                backbone = Unet(in_channels=4, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
+        elif dataset == 'LiTS':
+            if model_name == 'U':
+                backbone = Unet(in_channels=1, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
+        elif dataset == 'ISIC':
+            if model_name == 'U':
+                backbone = Unet2D(3, num_classes, compute_dtype=dtype)
+        elif dataset == 'DRIVE':
+            if model_name == 'U':
+                backbone = Unet2DDRIVE(3, num_classes, compute_dtype=dtype)
+        elif dataset in ('TOAR', 'HC'):
+            if model_name == 'U':
+                backbone = Unet2D(1, num_classes, compute_dtype=dtype)
+        else:
+            print('There is no this dataset')
+            raise NameError
+        if backbone is None:
+            print('There is no this model')
+            raise NameError
+        self.backbone = backbone
+        if torch.cuda.is_available():
+            self.backbone.to(torch.device('cuda', torch.cuda.current_device()))
+        self.classes = num_classes
+        self.disentangle = False
+        self.eps = 1e-10
+        self.lambda_epochs = args.lambda_epochs
+        self.total_epochs = args.end_epochs + 1
+        self.u_loss = args.Uncertainty_Loss
+
+    def forward(self, X, y, global_step, mode, dataset):
+        if mode == 'train':
+            logits = self.backbone.forward_channels_last(X)
+            if self.u_loss:
+                evidence = self.infer(ops_from_cl(logits))
+                alpha = evidence + 1
+                loss = dce_evidence_u_loss(y.to(torch.int64), alpha, self.classes, global_step, self.lambda_epochs,
+                                           self.total_epochs, self.eps, self.disentangle, evidence, None)
+                return evidence, torch.mean(loss)
+            evidence, loss = evidential_head_loss(logits, _labels(y), global_step, self.lambda_epochs,
+                                                  channels_last=True, want_evidence=True)
+            return evidence, loss
+        if dataset == 'BraTS':
+            out = tailor_and_concat(X, self.backbone)
+        else:
+            out = self.backbone(X)
+        return self.infer(out)
+
+    def infer(self, input):
+        """softplus evidence of NC(D)HW logits (TrustworthySeg.py:160-166)."""
+        return _SoftplusFn.apply(input)
+
+
+def _labels(y: torch.Tensor) -> torch.Tensor:
+    if y.dtype not in (torch.int64, torch.int32, torch.uint8):
+        y = y.to(torch.int64)          # the reference casts with y.to(torch.int64), TrustworthySeg.py:154
+    return y.contiguous()
+
+
+def ops_from_cl(logits_cl):
+    from .unet3d import _FromChannelsLast
+    return _FromChannelsLast.apply(logits_cl)
+
+
+class _SoftplusFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        z = z.contiguous().float()
+        ctx.save_for_backward(z)
+        return ops.evid_infer(z, False, (), want_evidence=True)["evidence"]
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        return ops.softplus_bwd(z, g.contiguous().float())

@@ -1,0 +1,300 @@
+"""3-D residual U-Net on MI355X: same constructor, attribute names and ``state_dict`` keys
+as the reference ``Unet`` (models/lib/UNet3DZoo.py:243-305), executed by the HIP kernels.
+
+The whole backbone is ONE autograd node (``_Unet3dFn``): forward and backward are explicit
+schedules of C-ABI calls over channels-last activations, so that
+  * GroupNorm/BatchNorm-apply + ReLU run in the consuming conv's prologue
+    (the normalised tensor is never written to HBM),
+  * residual adds and the skip-gradient adds run in conv / norm-backward epilogues,
+  * ``torch.cat`` (UNet3DZoo.py:128) is a two-pointer K loop inside the 1x1 conv.
+nn.Conv3d / nn.GroupNorm / nn.BatchNorm3d objects are used as parameter holders only
+(identical init order => identical weights for a given torch seed); they are never called.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ConvGeom
+
+Tensor = torch.Tensor
+
+G3 = ConvGeom((3, 3, 3), (1, 1, 1), (1, 1, 1))
+G3S2 = ConvGeom((3, 3, 3), (2, 2, 2), (1, 1, 1))
+G1 = ConvGeom((1, 1, 1), (1, 1, 1), (0, 0, 0))
+
+
+# ------------------------------------------------------------ parameter holders
+class _InitConv(nn.Module):          # UNet3DZoo.py:21-32 (dropout p = 0 in Unet => identity, no RNG draw)
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, kernel_size=3, padding=1)
+
+
+class _EnBlock(nn.Module):           # UNet3DZoo.py:35-56
+    def __init__(self, c):
+        super().__init__()
+        self.bn1 = nn.GroupNorm(8, c)
+        self.conv1 = nn.Conv3d(c, c, kernel_size=3, padding=1)
+        self.bn2 = nn.GroupNorm(8, c)
+        self.conv2 = nn.Conv3d(c, c, kernel_size=3, padding=1)
+
+
+class _EnDown(nn.Module):            # UNet3DZoo.py:59-67
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, kernel_size=3, stride=2, padding=1)
+
+
+class _DeUpCat(nn.Module):           # UNet3DZoo.py:117-130
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv3d(cin, cout, kernel_size=1)
+        self.conv2 = nn.ConvTranspose3d(cout, cout, kernel_size=2, stride=2)
+        self.conv3 = nn.Conv3d(cin, cout, kernel_size=1)
+
+
+class _DeBlock(nn.Module):           # UNet3DZoo.py:145-165
+    def __init__(self, c):
+        super().__init__()
+        self.bn1 = nn.BatchNorm3d(c)
+        self.conv1 = nn.Conv3d(c, c, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv3d(c, c, kernel_size=3, padding=1)
+        self.bn2 = nn.BatchNorm3d(c)
+
+
+# ------------------------------------------------------------ explicit schedule
+class _Run:
+    """One forward (and, if taped, backward) pass of the 3-D U-Net over channels-last tensors."""
+
+    def __init__(self, params: Dict[str, Tensor], buffers: Dict[str, Tensor], dtype, training: bool, tape: bool):
+        self.P, self.B = params, buffers
+        self.dtype, self.training, self.taping = dtype, training, tape
+        self.tape: List = []
+        self.grads: Dict[str, Tensor] = {}
+
+    # ---- helpers
+    def _w(self, name):
+        return ops.pack_conv_weight(self.P[name + ".weight"], self.dtype)
+
+    def _push(self, *entry):
+        if self.taping:
+            self.tape.append(entry)
+
+    def _gn(self, name, x):
+        return ops.gn_stats(x, self.P[name + ".weight"], self.P[name + ".bias"])
+
+    def _bn(self, name, x):
+        if self.training:
+            self.B[name + ".num_batches_tracked"].add_(1)
+        return ops.bn_stats(x, self.P[name + ".weight"], self.P[name + ".bias"],
+                            self.B[name + ".running_mean"], self.B[name + ".running_var"], self.training)
+
+    # ---- forward blocks
+    def conv(self, name, x, geom):
+        wp = self._w(name)
+        y = ops.conv_fwd(x, None, wp, self.P[name + ".bias"], geom)
+        self._push("conv", name, x, wp, geom)
+        return y
+
+    def en_block(self, name, x):
+        st1 = self._gn(name + ".bn1", x)
+        w1 = self._w(name + ".conv1")
+        h = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G3, st1[0], st1[1])
+        st2 = self._gn(name + ".bn2", h)
+        w2 = self._w(name + ".conv2")
+        out = ops.conv_fwd(h, None, w2, self.P[name + ".conv2.bias"], G3, st2[0], st2[1], residual=x)
+        self._push("en", name, x, h, st1, st2, w1, w2)
+        return out
+
+    def de_block(self, name, x):
+        w1 = self._w(name + ".conv1")
+        h1 = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G3)
+        st1 = self._bn(name + ".bn1", h1)
+        w2 = self._w(name + ".conv2")
+        h2 = ops.conv_fwd(h1, None, w2, self.P[name + ".conv2.bias"], G3, st1[0], st1[1])
+        st2 = self._bn(name + ".bn2", h2)
+        out = ops.affine_act(h2, st2[0], st2[1], residual=x, relu=True)
+        self._push("de", name, x, h1, h2, st1, st2, w1, w2)
+        return out
+
+    def de_up_cat(self, name, x, prev):
+        w1 = self._w(name + ".conv1")
+        t = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G1)
+        wt = ops.pack_convT_weight(self.P[name + ".conv2.weight"], self.dtype)
+        up = ops.convT_fwd(t, wt, self.P[name + ".conv2.bias"], (2, 2, 2))
+        w3 = self._w(name + ".conv3")
+        y = ops.conv_fwd(prev, up, w3, self.P[name + ".conv3.bias"], G1)     # virtual cat((prev, up))
+        self._push("up", name, x, prev, t, up, w1, wt, w3)
+        return y
+
+    def forward(self, x: Tensor) -> Tensor:
+        h = self.conv("InitConv.conv", x, G3)
+        s1 = self.en_block("EnBlock1", h)
+        h = self.conv("EnDown1.conv", s1, G3S2)
+        h = self.en_block("EnBlock2_1", h)
+        s2 = self.en_block("EnBlock2_2", h)
+        h = self.conv("EnDown2.conv", s2, G3S2)
+        h = self.en_block("EnBlock3_1", h)
+        s3 = self.en_block("EnBlock3_2", h)
+        h = self.conv("EnDown3.conv", s3, G3S2)
+        for i in (1, 2, 3, 4):
+            h = self.en_block("EnBlock4_%d" % i, h)
+        h = self.de_block("DeBlock4", self.de_up_cat("DeUpCat4", h, s3))
+        h = self.de_block("DeBlock3", self.de_up_cat("DeUpCat3", h, s2))
+        h = self.de_block("DeBlock2", self.de_up_cat("DeUpCat2", h, s1))
+        return self.conv("endconv", h, G1)
+
+    # ---- backward blocks
+    def _conv_bwd(self, e, dy, need_dx=True):
+        _, name, x, wp, geom = e
+        g = self.grads
+        g[name + ".weight"], g[name + ".bias"] = ops.conv_wgrad(x, None, dy, geom, self.P[name + ".weight"].shape)
+        return ops.conv_dgrad(dy, wp, geom, x.shape)[0] if need_dx else None
+
+    def _en_bwd(self, e, dout):
+        _, name, x, h, st1, st2, w1, w2 = e
+        g, P = self.grads, self.P
+        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
+            h, None, dout, G3, P[name + ".conv2.weight"].shape, st2[0], st2[1])
+        da = ops.conv_dgrad(dout, w2, G3, h.shape)[0]
+        dh, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
+            da, h, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 8, False)
+        g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
+            x, None, dh, G3, P[name + ".conv1.weight"].shape, st1[0], st1[1])
+        da = ops.conv_dgrad(dh, w1, G3, x.shape)[0]
+        dx, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
+            da, x, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 8, False, extra=dout)
+        return dx
+
+    def _de_bwd(self, e, dout):
+        _, name, x, h1, h2, st1, st2, w1, w2 = e
+        g, P = self.grads, self.P
+        dh2, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
+            dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, True)
+        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
+            h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1])
+        da = ops.conv_dgrad(dh2, w2, G3, h1.shape)[0]
+        dh1, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
+            da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, True)
+        g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
+            x, None, dh1, G3, P[name + ".conv1.weight"].shape)
+        return ops.add(ops.conv_dgrad(dh1, w1, G3, x.shape)[0], dout)
+
+    def _up_bwd(self, e, dy):
+        _, name, x, prev, t, up, w1, wt, w3 = e
+        g, P = self.grads, self.P
+        g[name + ".conv3.weight"], g[name + ".conv3.bias"] = ops.conv_wgrad(
+            prev, up, dy, G1, P[name + ".conv3.weight"].shape)
+        dprev, dup = ops.conv_dgrad(dy, w3, G1, prev.shape, up.shape[-1])
+        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.convT_wgrad(
+            t, dup, (2, 2, 2), P[name + ".conv2.weight"].shape)
+        dt = ops.convT_dgrad(dup, wt, (2, 2, 2), t.shape)
+        g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
+            x, None, dt, G1, P[name + ".conv1.weight"].shape)
+        dx = ops.conv_dgrad(dt, w1, G1, x.shape)[0]
+        return dx, dprev
+
+    def backward(self, dlogits: Tensor, need_dx: bool):
+        """Mirror of forward(); returns d(input) (or None) and fills self.grads."""
+        t = self.tape
+        pop = t.pop
+        d = self._conv_bwd(pop(), dlogits)                       # endconv
+        d = self._de_bwd(pop(), d); d, ds1 = self._up_bwd(pop(), d)   # DeBlock2, DeUpCat2
+        d = self._de_bwd(pop(), d); d, ds2 = self._up_bwd(pop(), d)   # DeBlock3, DeUpCat3
+        d = self._de_bwd(pop(), d); d, ds3 = self._up_bwd(pop(), d)   # DeBlock4, DeUpCat4
+        for _ in range(4):
+            d = self._en_bwd(pop(), d)                           # EnBlock4_4..1
+        d = ops.add(self._conv_bwd(pop(), d), ds3)               # EnDown3 (+ skip gradient)
+        d = self._en_bwd(pop(), d); d = self._en_bwd(pop(), d)
+        d = ops.add(self._conv_bwd(pop(), d), ds2)               # EnDown2
+        d = self._en_bwd(pop(), d); d = self._en_bwd(pop(), d)
+        d = ops.add(self._conv_bwd(pop(), d), ds1)               # EnDown1
+        d = self._en_bwd(pop(), d)                               # EnBlock1
+        return self._conv_bwd(pop(), d, need_dx)                 # InitConv
+
+
+class _Unet3dFn(torch.autograd.Function):
+    """x (NCDHW fp32) -> channels-last logits; the only autograd node of the backbone."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        names = model._param_names
+        P = dict(zip(names, params))
+        taping = any(ctx.needs_input_grad)
+        run = _Run(P, dict(model.named_buffers()), model.compute_dtype, model.training, taping)
+        logits = run.forward(ops.to_channels_last(x, model.compute_dtype))
+        ctx.run, ctx.names = run, names
+        ctx.need_dx = ctx.needs_input_grad[1]
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        run = ctx.run
+        if not run.taping or not run.tape:
+            raise RuntimeError("devis_amd Unet: backward called twice or without a taped forward")
+        dx_cl = run.backward(dlogits.contiguous(), ctx.need_dx)
+        dx = ops.from_channels_last(dx_cl) if dx_cl is not None else None
+        grads = tuple(run.grads.get(n) for n in ctx.names)
+        run.tape, run.grads = [], {}
+        return (None, dx) + grads
+
+
+class _FromChannelsLast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        ctx.dtype = y.dtype
+        return ops.from_channels_last(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.to_channels_last(g, ctx.dtype)
+
+
+class Unet(nn.Module):
+    """Drop-in for the reference ``Unet(in_channels, base_channels, num_classes)``.
+
+    ``forward(x)`` takes and returns NCDHW fp32 like the reference; ``forward_channels_last(x)``
+    returns the channels-last logits the fused evidential head consumes.
+    ``compute_dtype``: torch.bfloat16 (MFMA path) or torch.float32 (exact-arithmetic path).
+    """
+
+    def __init__(self, in_channels=1, base_channels=16, num_classes=4, compute_dtype=torch.bfloat16):
+        super().__init__()
+        b = base_channels
+        self.InitConv = _InitConv(in_channels, b)
+        self.EnBlock1 = _EnBlock(b)
+        self.EnDown1 = _EnDown(b, b * 2)
+        self.EnBlock2_1 = _EnBlock(b * 2)
+        self.EnBlock2_2 = _EnBlock(b * 2)
+        self.EnDown2 = _EnDown(b * 2, b * 4)
+        self.EnBlock3_1 = _EnBlock(b * 4)
+        self.EnBlock3_2 = _EnBlock(b * 4)
+        self.EnDown3 = _EnDown(b * 4, b * 8)
+        self.EnBlock4_1 = _EnBlock(b * 8)
+        self.EnBlock4_2 = _EnBlock(b * 8)
+        self.EnBlock4_3 = _EnBlock(b * 8)
+        self.EnBlock4_4 = _EnBlock(b * 8)
+        self.DeUpCat4 = _DeUpCat(b * 8, b * 4)
+        self.DeBlock4 = _DeBlock(b * 4)
+        self.DeUpCat3 = _DeUpCat(b * 4, b * 2)
+        self.DeBlock3 = _DeBlock(b * 2)
+        self.DeUpCat2 = _DeUpCat(b * 2, b)
+        self.DeBlock2 = _DeBlock(b)
+        self.endconv = nn.Conv3d(b, num_classes, kernel_size=1)
+        self.compute_dtype = compute_dtype
+        self.num_classes = num_classes
+        self._param_names = [n for n, _ in self.named_parameters()]
+
+    def forward_channels_last(self, x: Tensor) -> Tensor:
+        if x.dim() != 5 or x.shape[1] != self.InitConv.conv.in_channels:
+            raise ValueError("Unet expects (N, %d, D, H, W), got %s" % (self.InitConv.conv.in_channels, tuple(x.shape)))
+        if any(s % 8 for s in x.shape[2:]):
+            raise ValueError("Unet needs D, H, W divisible by 8 (three stride-2 stages), got %s" % (tuple(x.shape[2:]),))
+        return _Unet3dFn.apply(self, x, *[p for _, p in self.named_parameters()])
+
+    def forward(self, x: Tensor) -> Tensor:
+        return _FromChannelsLast.apply(self.forward_channels_last(x))

@@ -1,0 +1,197 @@
+/* devis_hip.h — C ABI of libdevis_hip.so, the MI355X (gfx950) kernels behind the
+ * DEviS evidential U-Net hot path.
+ *
+ * The reference (Cocofeat/DEviS) has no FFI: its hot path is a chain of implicit
+ * ATen/cuDNN launches issued from Python.  Each entry point
+ * below replaces the ATen op(s) named in its comment, cited as
+ * `file:line` relative to the reference root.  The Python host side
+ * (devis_amd/) binds these with ctypes inside torch.autograd.Function.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *  - activations are channels-last: [N][D][H][W][C] (2-D: D = 1), element type
+ *    selected by `dtype` (DEVIS_F32 / DEVIS_BF16); statistics, biases, norm
+ *    coefficients and parameter gradients are always fp32 (moments fp64);
+ *  - packed conv weights are [Cout][KD*KH*KW][Cin] in `dtype`
+ *    (devis_pack_conv_weight); parameter GRADIENTS are written in the
+ *    reference/PyTorch layout, fp32, so they can be handed to torch.optim.Adam;
+ *  - the caller owns every buffer including workspaces (size from the matching
+ *    *_workspace_bytes); the library never allocates, frees or synchronises;
+ *  - `stream` is a hipStream_t (0 = default stream);
+ *  - return value: DEVIS_OK or a negative devis_status; nothing throws.
+ */
+#ifndef DEVIS_HIP_H
+#define DEVIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum devis_status {
+  DEVIS_OK = 0,
+  DEVIS_ERR_BAD_ARG = -1,
+  DEVIS_ERR_UNSUPPORTED = -2,
+  DEVIS_ERR_HIP = -3,
+  DEVIS_ERR_WORKSPACE = -4
+};
+enum devis_dtype { DEVIS_F32 = 0, DEVIS_BF16 = 1 };
+enum devis_label_dtype { DEVIS_LABEL_I64 = 0, DEVIS_LABEL_U8 = 1, DEVIS_LABEL_I32 = 2 };
+
+int devis_version(void);
+/* last hipError_t seen by this thread (0 = hipSuccess) and its string */
+int devis_last_hip_error(void);
+const char* devis_last_hip_error_string(void);
+
+/* ---------------------------------------------------------------- layout -- */
+/* NC(D)HW fp32 -> channels-last `dtype`, and back.  Replaces the implicit
+ * layout of every reference tensor ("fp32 contiguous NCDHW"). */
+int devis_ncx_to_nxc(const float* src, void* dst, int64_t N, int64_t C, int64_t V, int dtype, void* stream);
+int devis_nxc_to_ncx(const void* src, float* dst, int64_t N, int64_t C, int64_t V, int dtype, void* stream);
+/* nn.Conv{2,3}d.weight [Cout][Cin][T] fp32 -> [Cout][T][Cin] dtype */
+int devis_pack_conv_weight(const float* w, void* dst, int64_t Cout, int64_t Cin, int64_t T, int dtype, void* stream);
+/* nn.ConvTranspose{2,3}d.weight [Cin][Cout][T] fp32 -> [T][Cout][Cin] dtype */
+int devis_pack_convT_weight(const float* w, void* dst, int64_t Cin, int64_t Cout, int64_t T, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ conv -- */
+typedef struct devis_conv_desc {
+  int64_t N;
+  int64_t ID, IH, IW;  /* input spatial size */
+  int64_t OD, OH, OW;  /* output spatial size */
+  int64_t C1, C2;      /* input channels taken from x1 and x2 (virtual concat; C2 = 0: none) */
+  int64_t Cout;
+  int32_t KD, KH, KW;
+  int32_t SD, SH, SW;
+  int32_t PD, PH, PW;
+  int32_t dtype;
+} devis_conv_desc;
+
+/* y = conv(relu(in_scale*x + in_shift)) + bias (+ residual).
+ * in_scale/in_shift: [N][C1+C2] fp32 or NULL (no prologue).  Zero padding is
+ * applied AFTER the prologue, as in the reference where the norm+ReLU output
+ * is what gets padded.
+ * Replaces nn.Conv3d / nn.Conv2d forward (UNet3DZoo.py:25,41,45,62,120,122,151,152,274;
+ * UNet2DZoo.py:12,15,128) fused with the preceding GroupNorm/BatchNorm apply +
+ * ReLU (UNet3DZoo.py:48-53,158-162), torch.cat (UNet3DZoo.py:128; UNet2DZoo.py:153,156,181)
+ * and the residual add (UNet3DZoo.py:54). */
+int devis_conv_fwd(const devis_conv_desc* d, const void* x1, const void* x2, const void* w_packed,
+                   const float* bias, const float* in_scale, const float* in_shift,
+                   const void* residual, void* y, void* stream);
+/* dA = conv_transpose(dy, w): gradient w.r.t. the conv's (post-prologue) input,
+ * split over the two virtual-concat inputs (dx2 may be NULL when C2 = 0).
+ * Replaces cuDNN dgrad of the same layers. */
+int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w_packed,
+                     void* dx1, void* dx2, void* stream);
+/* dw [Cout][C1+C2][T] fp32 (PyTorch layout) and dbias [Cout] fp32 (may be NULL).
+ * The conv input is recomputed from x1/x2 with the same prologue. */
+size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d);
+int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2,
+                     const float* in_scale, const float* in_shift, const void* dy,
+                     float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ConvTranspose with kernel == stride in every dim (k=2,s=2; 2-D: KD=1).
+ * Replaces nn.ConvTranspose3d (UNet3DZoo.py:121) / nn.ConvTranspose2d (UNet2DZoo.py:120-126).
+ * w_packed: [T][Cout][Cin] (devis_pack_convT_weight); dw: [Cin][Cout][T] fp32. */
+typedef struct devis_convT_desc {
+  int64_t N;
+  int64_t ID, IH, IW;
+  int64_t Cin, Cout;
+  int32_t KD, KH, KW; /* each 1 or 2; output size = input size * K */
+  int32_t dtype;
+} devis_convT_desc;
+int devis_convT_fwd(const devis_convT_desc* d, const void* x, const void* w_packed, const float* bias,
+                    void* y, void* stream);
+int devis_convT_dgrad(const devis_convT_desc* d, const void* dy, const void* w_packed, void* dx, void* stream);
+size_t devis_convT_wgrad_workspace_bytes(const devis_convT_desc* d);
+int devis_convT_wgrad(const devis_convT_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------- normalisation -- */
+/* per-(n,c) moments of a channels-last tensor: out[n][c] = {sum x, sum x^2} (fp64).
+ * First half of nn.GroupNorm / nn.BatchNorm forward (UNet3DZoo.py:12,149,153; UNet2DZoo.py:13,16). */
+size_t devis_moments_workspace_bytes(int64_t N, int64_t V, int64_t C);
+int devis_channel_moments(const void* x, int64_t N, int64_t V, int64_t C, int dtype, double* out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* GroupNorm(G, C): moments -> per-(n,c) affine  y = scale*x + shift, plus mean/rstd [N][G]. */
+int devis_gn_finalize(const double* moments, int64_t N, int64_t V, int64_t C, int64_t G,
+                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                      float* mean, float* rstd, void* stream);
+/* BatchNorm: training != 0 -> batch statistics (+ running-stat update, momentum, unbiased var);
+ * training == 0 -> running statistics (moments may be NULL).  scale/shift are [N][C] (rows equal),
+ * mean/rstd are [C]. */
+int devis_bn_finalize(const double* moments, int64_t N, int64_t V, int64_t C, const float* gamma,
+                      const float* beta, float eps, float momentum, int training, float* running_mean,
+                      float* running_var, float* scale, float* shift, float* mean, float* rstd,
+                      void* stream);
+/* y = [relu](scale*x + shift) (+ residual): materialised norm+ReLU (+ residual add, UNet3DZoo.py:163). */
+int devis_affine_act(const void* x, const float* scale, const float* shift, const void* residual,
+                     void* y, int64_t N, int64_t V, int64_t C, int dtype, int relu, void* stream);
+/* backward: dy' = dy * [scale*x+shift > 0];  out[n][c] = {sum dy', sum dy'*x} (fp64) */
+int devis_norm_bwd_moments(const void* dy, const void* x, const float* scale, const float* shift,
+                           int64_t N, int64_t V, int64_t C, int dtype, double* out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* moments -> dx = cA*dy' + cB*x + cC  coefficients [N][C], and dgamma/dbeta [C].
+ * `bn` = 0: GroupNorm with G groups (mean/rstd [N][G]); 1: BatchNorm (mean/rstd [C]). */
+int devis_norm_bwd_finalize(const double* moments, int64_t N, int64_t V, int64_t C, int64_t G, int bn,
+                            const float* gamma, const float* mean, const float* rstd, float* cA,
+                            float* cB, float* cC, float* dgamma, float* dbeta, void* stream);
+/* dx = cA*dy' + cB*x + cC (+ extra): autograd of group_norm/batch_norm + relu (+ skip gradient) */
+int devis_norm_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
+                         const float* cA, const float* cB, const float* cC, const void* extra, void* dx,
+                         int64_t N, int64_t V, int64_t C, int dtype, void* stream);
+/* z = a + b: elementwise add of two channels-last tensors (skip-gradient accumulation) */
+int devis_add(const void* a, const void* b, void* z, int64_t n_elems, int dtype, void* stream);
+
+/* nn.MaxPool2d(2) (UNet2DZoo.py:112-118), floor mode; idx = argmax position 0..3 inside the window */
+int devis_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int64_t N, int64_t H, int64_t W, int64_t C,
+                        int dtype, void* stream);
+int devis_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int64_t N, int64_t H, int64_t W,
+                        int64_t C, int dtype, void* stream);
+
+/* -------------------------------------------------- evidential head/loss -- */
+/* Element (n, v, k) of `logits` lives at logits[n*sN + v*sV + k*sK] (element strides), so both
+ * channels-last (sV=K, sK=1) and the reference's NC(D)HW (sV=1, sK=V) are accepted.
+ *
+ * devis_evid_loss_fwd replaces TMSU.forward's head + dce_evidence_loss
+ * (TrustworthySeg.py:144-155; criterions.py:421-456,117-127,226-257,353-370):
+ *   e = softplus(z), alpha = e+1, loss = mean_v(L_ace + lambda*KL) + L_dice.
+ * scal (fp32, DEVIS_EVID_SCAL_FLOATS entries) receives
+ *   [0] loss  [1] L_dice  [2] mean_v(L_ace + lambda*KL)  [3] NV
+ *   [4+k] I_k  [4+K+k] P_k  [4+2K+k] R_k            (k < K <= DEVIS_EVID_MAX_K)
+ * evidence_out: optional NC(D)HW fp32 copy of the evidence (returned by TMSU.forward in train mode).
+ * per_voxel_out: optional [N*V] fp32 = L_ace + lambda*KL per voxel (the (NV,1) tensor of
+ *   criterions.py:456 minus the broadcast L_dice). */
+#define DEVIS_EVID_MAX_K 8
+#define DEVIS_EVID_SCAL_FLOATS (4 + 3 * DEVIS_EVID_MAX_K)
+size_t devis_evid_workspace_bytes(int64_t N, int64_t V, int64_t K);
+int devis_evid_loss_fwd(const void* logits, int64_t sN, int64_t sV, int64_t sK, int dtype,
+                        const void* labels, int label_dtype, int64_t N, int64_t V, int64_t K,
+                        float lambda, float* evidence_out, float* per_voxel_out, float* scal,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* dlogits (same strides/dtype as logits) = grad_loss * dloss/dz  [+ grad_evidence * sigmoid(z)]
+ * grad_loss: device pointer to one fp32;  grad_evidence: optional NC(D)HW fp32.
+ * grad_per_voxel: optional [N*V] fp32 upstream gradient of the (NV,1) tensor (then grad_loss is
+ *   ignored for the per-voxel terms and `grad_dice` (device fp32 scalar) scales the dice term). */
+int devis_evid_loss_bwd(const void* logits, int64_t sN, int64_t sV, int64_t sK, int dtype,
+                        const void* labels, int label_dtype, int64_t N, int64_t V, int64_t K,
+                        float lambda, const float* scal, const float* grad_loss,
+                        const float* grad_per_voxel, const float* grad_dice,
+                        const float* grad_evidence, void* dlogits, void* stream);
+/* val/test head (trainUMIS.py:286-290,446-451,521; predict.py:92-105):
+ *   evidence (optional, NC(D)HW fp32), pred = argmax_k alpha_k/S (first max; uint8),
+ *   u = K/S (fp32), mne = normalised entropy over classes >= 1 (optional fp32),
+ *   umask bit i = [u > thresholds[i]] (optional uint16, n_thr <= 16). */
+int devis_evid_infer(const void* logits, int64_t sN, int64_t sV, int64_t sK, int dtype, int64_t N,
+                     int64_t V, int64_t K, float* evidence_out, uint8_t* pred, float* u, float* mne,
+                     uint16_t* umask, const float* thresholds_host, int n_thr, void* stream);
+
+/* dz = g * d softplus(z)/dz, fp32 flat arrays: autograd of TMSU.infer (TrustworthySeg.py:160-166)
+ * when the evidence is consumed outside the fused loss. */
+int devis_softplus_bwd(const float* z, const float* g, float* dz, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEVIS_HIP_H */

@@ -1,0 +1,218 @@
+"""GPU unit parity: every C-ABI op against the same torch op evaluated on the CPU in fp32/fp64
+(the plain-PyTorch statement of what the reference's nn.Module would compute)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def cl(t, dtype=torch.float32):     # NC... (cpu) -> channels-last on GPU
+    perm = (0,) + tuple(range(2, t.dim())) + (1,)
+    return t.permute(*perm).contiguous().to(dtype).cuda()
+
+
+def uncl(t):                        # channels-last GPU -> NC... cpu fp32
+    perm = (0, t.dim() - 1) + tuple(range(1, t.dim() - 1))
+    return t.float().permute(*perm).contiguous().cpu()
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2e-2
+
+
+CONV_CASES = [
+    # (N, Cin1, Cin2, Cout, spatial, kernel, stride, pad)
+    (2, 4, 0, 16, (6, 8, 10), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 16, 0, 32, (8, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (1, 32, 0, 32, (4, 6, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 16, 16, 16, (4, 4, 6), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    (2, 16, 0, 4, (4, 4, 6), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    (2, 8, 24, 16, (9, 11), (3, 3), (1, 1), (1, 1)),
+    (3, 3, 0, 32, (12, 7), (3, 3), (1, 1), (1, 1)),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("prologue", [False, True])
+def test_conv_fwd_dgrad_wgrad(case, dtype, prologue):
+    from devis_amd import ops
+    n, c1, c2, co, sp, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    nd = len(sp)
+    x = torch.randn((n, c1 + c2) + sp, generator=g)
+    w = torch.randn((co, c1 + c2) + k, generator=g) * 0.2
+    b = torch.randn((co,), generator=g)
+    sc = torch.rand((n, c1 + c2), generator=g) + 0.5
+    sh = torch.randn((n, c1 + c2), generator=g) * 0.3
+    if dtype == torch.bfloat16:      # compare on the rounded operands
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    conv = F.conv3d if nd == 3 else F.conv2d
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    a = xr
+    if prologue:
+        shape = (n, c1 + c2) + (1,) * nd
+        a = F.relu(xr * sc.view(shape) + sh.view(shape))
+    yr = conv(a, wr, br, stride=s, padding=p)
+    res = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        res = res.bfloat16().float()
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    a.retain_grad()
+    (yr + res).backward(dy)
+
+    geom = ops.ConvGeom(k, s, p)
+    x1 = cl(x[:, :c1], dtype)
+    x2 = cl(x[:, c1:], dtype) if c2 else None
+    wp = ops.pack_conv_weight(w.cuda(), dtype)
+    scg, shg = (sc.cuda().contiguous(), sh.cuda().contiguous()) if prologue else (None, None)
+    y = ops.conv_fwd(x1, x2, wp, b.cuda(), geom, scg, shg, residual=cl(res, dtype))
+    assert rel_err(uncl(y), (yr + res).detach()) < tol(dtype)
+    dx1, dx2 = ops.conv_dgrad(cl(dy, dtype), wp, geom, x1.shape, c2)
+    da = a.grad
+    assert rel_err(uncl(dx1), da[:, :c1]) < tol(dtype)
+    if c2:
+        assert rel_err(uncl(dx2), da[:, c1:]) < tol(dtype)
+    dw, db = ops.conv_wgrad(x1, x2, cl(dy, dtype), geom, w.shape, scg, shg)
+    assert rel_err(dw, wr.grad) < tol(dtype)
+    assert rel_err(db, br.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 16, 8, (3, 4, 5), (2, 2, 2)), (2, 32, 16, (5, 6), (2, 2)), (1, 64, 64, (2, 2, 2), (2, 2, 2))])
+def test_convT(case, dtype):
+    from devis_amd import ops
+    n, ci, co, sp, k = case
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((n, ci) + sp, generator=g)
+    w = torch.randn((ci, co) + k, generator=g) * 0.2
+    b = torch.randn((co,), generator=g)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    fn = F.conv_transpose3d if len(sp) == 3 else F.conv_transpose2d
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = fn(xr, wr, br, stride=2)
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy)
+    wp = ops.pack_convT_weight(w.cuda(), dtype)
+    xg = cl(x, dtype)
+    y = ops.convT_fwd(xg, wp, b.cuda(), k)
+    assert rel_err(uncl(y), yr.detach()) < tol(dtype)
+    dx = ops.convT_dgrad(cl(dy, dtype), wp, k, xg.shape)
+    assert rel_err(uncl(dx), xr.grad) < tol(dtype)
+    dw, db = ops.convT_wgrad(xg, cl(dy, dtype), k, w.shape)
+    assert rel_err(dw, wr.grad) < tol(dtype)
+    assert rel_err(db, br.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["gn", "bn"])
+@pytest.mark.parametrize("shape", [(2, 16, 4, 6, 5), (3, 32, 7, 9), (1, 128, 2, 3, 4), (2, 512, 4, 4)])
+def test_norm_relu_fwd_bwd(shape, kind, dtype):
+    from devis_amd import ops
+    g = torch.Generator().manual_seed(8)
+    n, c = shape[0], shape[1]
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    gamma = torch.rand((c,), generator=g) + 0.5
+    beta = torch.randn((c,), generator=g) * 0.2
+    rm0 = torch.randn((c,), generator=g) * 0.1
+    rv0 = torch.rand((c,), generator=g) + 0.5
+    extra = torch.randn(shape, generator=g)
+    dy = torch.randn(shape, generator=g)
+    if dtype == torch.bfloat16:
+        extra, dy = extra.bfloat16().float(), dy.bfloat16().float()
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    if kind == "gn":
+        yr = F.relu(F.group_norm(xr, 8, gr, br, 1e-5))
+    else:
+        yr = F.relu(F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5))
+    (yr + xr * 0).backward(dy.double())
+    dxr = xr.grad + extra.double()
+
+    xg = cl(x, dtype)
+    gg, bg = gamma.cuda(), beta.cuda()
+    if kind == "gn":
+        sc, sh, mean, rstd = ops.gn_stats(xg, gg, bg)
+        groups, bn = 8, False
+    else:
+        rmg, rvg = rm0.cuda(), rv0.cuda()
+        sc, sh, mean, rstd = ops.bn_stats(xg, gg, bg, rmg, rvg, True)
+        groups, bn = 0, True
+        assert rel_err(rmg, rm) < 1e-5 and rel_err(rvg, rv) < 1e-5
+    y = ops.affine_act(xg, sc, sh, relu=True)
+    assert rel_err(uncl(y), yr.detach()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    dx, dgm, dbt = ops.norm_relu_bwd(cl(dy, dtype), xg, sc, sh, gg, mean, rstd, groups, bn, extra=cl(extra, dtype))
+    t = 2e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(uncl(dx), dxr) < t
+    assert rel_err(dgm, gr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert rel_err(dbt, br.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+def test_bn_eval_mode():
+    from devis_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((2, 32, 5, 6, 4), generator=g)
+    gamma, beta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    rm, rv = torch.randn(32, generator=g), torch.rand(32, generator=g) + 0.5
+    yr = F.relu(F.batch_norm(x, rm.clone(), rv.clone(), gamma, beta, False, 0.1, 1e-5))
+    rmg, rvg = rm.cuda(), rv.cuda()
+    sc, sh, _, _ = ops.bn_stats(cl(x), gamma.cuda(), beta.cuda(), rmg, rvg, False)
+    y = ops.affine_act(cl(x), sc, sh, relu=True)
+    assert rel_err(uncl(y), yr) < 1e-6
+    assert torch.equal(rmg.cpu(), rm) and torch.equal(rvg.cpu(), rv)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 32, 8, 10), (1, 64, 9, 7), (2, 16, 5, 12)])
+def test_maxpool(shape, dtype):
+    from devis_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = F.relu(torch.randn(shape, generator=g))          # ReLU zeros create ties: first max must win
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xg = cl(x, dtype)
+    y, idx = ops.maxpool2d_fwd(xg)
+    assert torch.equal(uncl(y), yr.detach())
+    dx = ops.maxpool2d_bwd(cl(dy, torch.float32).to(dtype), idx, xg.shape)
+    ref = xr.grad if dtype == torch.float32 else xr.grad.bfloat16().float()
+    assert rel_err(uncl(dx), ref) < (1e-7 if dtype == torch.float32 else 1e-2)
+
+
+def test_layout_roundtrip_and_add():
+    from devis_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((2, 5, 3, 4, 6), generator=g).cuda()
+    for dt in (torch.float32, torch.bfloat16):
+        y = ops.to_channels_last(x, dt)
+        assert y.shape == (2, 3, 4, 6, 5)
+        assert torch.equal(y.float(), x.permute(0, 2, 3, 4, 1).to(dt).float())
+        assert torch.equal(ops.from_channels_last(y), x.to(dt).float())
+        z = ops.add(y, y)
+        assert torch.equal(z.float(), (y.float() * 2).to(dt).float())
+
+
+def test_bad_arguments_fail_loudly():
+    from devis_amd import ops, _lib
+    with pytest.raises(_lib.DevisError):
+        ops.to_channels_last(torch.zeros(1, 2, 4, 4, 4), torch.float32)          # CPU tensor: no fallback
+    x = torch.zeros((1, 4, 4, 4, 16), device="cuda")
+    wp = torch.zeros((16, 27, 8), device="cuda")
+    with pytest.raises(_lib.DevisError):
+        ops.conv_fwd(x, None, wp, None, ops.ConvGeom((3, 3, 3), (1, 1, 1), (1, 1, 1)))   # channel mismatch

@@ -1,0 +1,126 @@
+"""GPU parity: 3-D U-Net + fused evidential head/loss vs the golden vectors (generated from the
+real reference) and vs the CPU oracle run live on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import brats_args, rel_err, sd_hash
+
+pytestmark = pytest.mark.gpu
+
+WATCH = ["endconv.weight", "endconv.bias", "InitConv.conv.weight", "EnBlock4_4.conv2.weight",
+         "EnBlock1.bn1.weight", "EnBlock2_1.bn2.bias", "EnDown2.conv.weight", "DeUpCat3.conv2.weight",
+         "DeUpCat2.conv3.weight", "DeBlock2.bn2.weight", "DeBlock3.conv1.weight", "DeBlock4.bn1.bias"]
+
+
+def _make(seed, dtype):
+    from devis_amd import TMSU
+    torch.manual_seed(seed)
+    m = TMSU(brats_args(compute_dtype=dtype))
+    m.train()
+    return m
+
+
+def _inputs(seed, shape):
+    g = torch.Generator().manual_seed(1000 + seed)
+    x = torch.randn(shape, generator=g)
+    y = torch.randint(0, 4, (shape[0],) + tuple(shape[2:]), generator=g)
+    return x, y
+
+
+CASES = [(0, 1), (0, 25), (0, 80), (1, 25), (2, 25)]
+
+
+@pytest.mark.parametrize("seed,epoch", CASES)
+def test_train_step_fp32_vs_golden(golden, seed, epoch):
+    G = golden("unet3d")
+    pre = "s%d_e%d_" % (seed, epoch)
+    shape = tuple(int(v) for v in G[pre + "shape"])
+    m = _make(seed, torch.float32)
+    assert sd_hash({k: v.cpu() for k, v in m.backbone.state_dict().items()}) == str(G[pre + "sd_hash"]), \
+        "seeded init differs from the reference's"
+    x, y = _inputs(seed, shape)
+    ev, loss = m(x.cuda(), y.cuda(), epoch, 'train', 'BraTS')
+    loss.requires_grad_(True).backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(G[pre + "loss"])) < 1e-5 * abs(float(G[pre + "loss"])) + 1e-6
+    if pre + "evidence" in G.files:
+        assert rel_err(ev.detach()[..., ::2], G[pre + "evidence"]) < 2e-5     # logits/alpha: 1e-5-class in fp32
+    params = dict(m.backbone.named_parameters())
+    for k in WATCH:
+        g = params[k].grad
+        g = g.reshape(-1)[::37] if g.numel() > 20000 else g
+        assert rel_err(g, G[pre + "grad_" + k]) < 2e-4, k
+    norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
+    # biases that feed a norm layer have mathematically-zero gradients (pure rounding noise): atol covers them
+    ref = G[pre + "gradnorm_all"]
+    assert np.all(np.abs(norms - ref) <= 2e-4 * ref + 1e-6 * ref.max()), np.max(np.abs(norms - ref) / (ref + 1e-30))
+    sd = m.backbone.state_dict()
+    for k in ("DeBlock2.bn2.running_mean", "DeBlock2.bn2.running_var", "DeBlock4.bn1.running_mean",
+              "DeBlock4.bn1.running_var"):
+        assert rel_err(sd[k], G[pre + "buf_" + k]) < 1e-5, k
+    assert int(sd["DeBlock2.bn2.num_batches_tracked"]) == 1
+    if pre + "eval_logits" in G.files:
+        m.eval()
+        with torch.no_grad():
+            lg = m.backbone(x.cuda())
+        assert rel_err(lg[..., ::2], G[pre + "eval_logits"]) < 2e-5
+
+
+def test_train_step_bf16_vs_golden(golden):
+    G = golden("unet3d")
+    pre = "s0_e25_"
+    shape = tuple(int(v) for v in G[pre + "shape"])
+    m = _make(0, torch.bfloat16)
+    x, y = _inputs(0, shape)
+    ev, loss = m(x.cuda(), y.cuda(), 25, 'train', 'BraTS')
+    loss.backward()
+    assert abs(loss.item() - float(G[pre + "loss"])) < 1e-3                     # north_star: loss within 1e-3
+    assert rel_err(ev.detach()[..., ::2], G[pre + "evidence"]) < 2e-2          # alpha within 1e-2-class
+    params = dict(m.backbone.named_parameters())
+    norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
+    ref = G[pre + "gradnorm_all"]
+    assert np.all(np.abs(norms - ref) <= 0.08 * ref + 1e-3 * ref.max()), np.max(np.abs(norms - ref) / (ref + 1e-12))
+
+
+def test_backbone_matches_oracle_live():
+    """Oracle run live on the GPU box's CPU, odd-shaped volume, batch 2, fp32."""
+    from oracle import devis_oracle as O
+    from devis_amd import Unet
+    torch.manual_seed(5)
+    net = Unet(4, 16, 4, compute_dtype=torch.float32)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.cuda().train()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((2, 4, 8, 24, 16), generator=g)
+    out = net(x.cuda())
+    ref = O.unet3d_forward(sd, x, True)
+    assert rel_err(out.detach(), ref) < 2e-5
+    for k in ("DeBlock3.bn1.running_var", "DeBlock2.bn2.running_mean"):
+        assert rel_err(net.state_dict()[k], sd[k]) < 1e-5
+
+
+def test_input_gradient_fp32():
+    from oracle import devis_oracle as O
+    from devis_amd import Unet
+    torch.manual_seed(6)
+    net = Unet(1, 16, 3, compute_dtype=torch.float32)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.cuda().train()
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn((1, 1, 16, 16, 16), generator=g)
+    w = torch.randn((1, 3, 16, 16, 16), generator=g)
+    xg = x.cuda().requires_grad_(True)
+    (net(xg) * w.cuda()).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    (O.unet3d_forward(sd, xr, True) * w).sum().backward()
+    assert rel_err(xg.grad, xr.grad) < 2e-4
+
+
+def test_shape_errors():
+    from devis_amd import Unet
+    net = Unet(4, 16, 4).cuda()
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 4, 12, 16, 16).cuda())
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 16, 16, 16).cuda())
