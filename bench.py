@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py - BraTS-shaped evidential 3-D U-Net training throughput on MI355X.
+
+One "step" = the reference's hot loop body (trainUMIS.py:244-262) on one synthetic batch:
+poly-LR update, TMSU forward (backbone + fused evidential head/loss), backward, gradient
+all-reduce over RCCL when WORLD_SIZE > 1, Adam step.  Metric: train voxels/s, whole job.
+
+    python bench.py --gpus 1 --steps 30 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     - the dominant kernel timed live with HIP events on the launch stream,
+  cpu_baseline - the CPU oracle (oracle/devis_oracle.py) timed on a bounded sample (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0          # HBM3E spec, same table
+FLOP_PER_VOXEL_FWD_BWD = 428160  # conv FLOPs fwd+bwd per voxel of the 3-D U-Net
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2, help="samples per GPU (reference default 2, trainUMIS.py:1360)")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def brats_args(dtype):
+    return argparse.Namespace(num_classes=4, dataset='BraTS', model_name='U', input_modality='four', end_epochs=99,
+                              lambda_epochs=50, Uncertainty_Loss=False, compute_dtype=dtype, lr=0.002)
+
+
+def kernel_probe(batch, size, dtype):
+    """Time the dominant kernel family (3x3x3 conv, 16->16 channels at full resolution) with HIP events
+    on the stream the kernels are launched on (torch's current stream)."""
+    from devis_amd import ops
+    from devis_amd.unet3d import G3
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((batch, size, size, size, 16), generator=g).to(dtype).to(dev)
+    dy = torch.randn((batch, size, size, size, 16), generator=g).to(dtype).to(dev)
+    w = (torch.randn((16, 16, 3, 3, 3), generator=g) * 0.05).to(dev)
+    b = torch.zeros(16, device=dev)
+    wp = ops.pack_conv_weight(w, dtype)
+    sc = torch.ones((batch, 16), device=dev)
+    sh = torch.zeros((batch, 16), device=dev)
+    vox = batch * size ** 3
+    flops = 2.0 * 27 * 16 * 16 * vox
+    esz = 2 if dtype == torch.bfloat16 else 4
+    res = {}
+
+    def timeit(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    res["conv3d_fwd_c16"] = (timeit(lambda: ops.conv_fwd(x, None, wp, b, G3, sc, sh)), flops, vox * 16 * esz * 2)
+    res["conv3d_dgrad_c16"] = (timeit(lambda: ops.conv_dgrad(dy, wp, G3, x.shape)), flops, vox * 16 * esz * 2)
+    res["conv3d_wgrad_c16"] = (timeit(lambda: ops.conv_wgrad(x, None, dy, G3, w.shape, sc, sh)), flops, vox * 16 * esz * 2)
+    return res
+
+
+def cpu_baseline(steps, size):
+    """The CPU oracle's train step (fwd + evidential loss + bwd + Adam) on B=1, timed on the host cores."""
+    from oracle import devis_oracle as O
+    from devis_amd import Unet
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in Unet(4, 16, 4).state_dict().items()}
+    params = []
+    for k in sd:
+        if sd[k].is_floating_point() and k.split('.')[-1] in ("weight", "bias"):
+            sd[k].requires_grad_(True)
+            params.append(sd[k])
+    opt = torch.optim.Adam(params, lr=0.002, weight_decay=1e-5)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn((1, 4, size, size, size), generator=g)
+    y = torch.randint(0, 4, (1, size, size, size), generator=g)
+    cores = os.cpu_count() if "OMP_NUM_THREADS" not in os.environ else int(os.environ["OMP_NUM_THREADS"])
+    torch.set_num_threads(cores)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.time()
+        _, loss = O.tmsu_forward(lambda t: O.unet3d_forward(sd, t, True), x, y, 25, 'train', 'BraTS', 4, 50, 100)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if i > 0:
+            times.append(time.time() - t0)
+    dt = sum(times) / len(times)
+    return {"value": size ** 3 / dt, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d steps of B=1 4x%d^3 K=4 fp32, oracle/devis_oracle.py (pinned bit-exact to the reference), "
+                      "%.2f s/step" % (steps, size, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from devis_amd import TMSU
+    from devis_amd.parallel import GradientAllReducer
+    from devis_amd.train import adjust_learning_rate
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    args = brats_args(dtype)
+    torch.manual_seed(0)                       # identical replicas on every rank
+    model = TMSU(args)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=1e-5)     # trainUMIS.py:1394
+    reducer = GradientAllReducer(model.parameters()) if world > 1 else None
+    g = torch.Generator().manual_seed(1234 + rank)
+    S = a.size
+    x = torch.randn((a.batch, 4, S, S, S), generator=g).to(dev)
+    y = torch.randint(0, 4, (a.batch, S, S, S), generator=g).to(dev)
+    epoch = 25
+
+    def step():
+        adjust_learning_rate(opt, epoch, args.end_epochs, args.lr)
+        _, loss = model(x, y, epoch, 'train', 'BraTS')
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        loss = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = float(loss.item())
+    vox = world * a.batch * S ** 3 * a.steps
+    out = {
+        "metric": "train voxels/sec (fwd+bwd+evid loss), BraTS 4x128^3 K=4",
+        "value": vox / dt, "unit": "voxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "configs[2]/[3]: BraTS2019-shaped 3D U-Net(4,16,4) evidential training, "
+                               "B=%d/GPU x 4x%d^3, K=4, epoch 25 (lambda 0.5), Adam+L2" % (a.batch, S),
+                   "global_batch": world * a.batch, "parallelism": "dp%d" % world},
+        "final_loss": final_loss,
+        "conv_mfma_frac_of_step": FLOP_PER_VOXEL_FWD_BWD * (vox / dt) / world / (PEAK_BF16_TFLOPS * 1e12),
+    }
+    if rank == 0:
+        probe = kernel_probe(a.batch, S, dtype)
+        name = max(probe, key=lambda k: probe[k][0])
+        t, flops, _bytes = probe[name]
+        out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": flops / t / 1e12, "peak": PEAK_BF16_TFLOPS,
+                           "unit": "TFLOP/s", "frac": flops / t / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                           "avg_launch_ms": t * 1e3,
+                           "all": {k: {"ms": v[0] * 1e3, "TFLOP/s": v[1] / v[0] / 1e12, "GB/s_alg": v[2] / v[0] / 1e9}
+                                   for k, v in probe.items()}}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_steps, S)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+"""Train / val drivers with the call surface of the reference's trainUMIS.py (train :239, val :265,
+adjust_learning_rate :217, AverageMeter :221, getArgs :35).  Data loaders are the caller's: anything
+yielding (input NC(D)HW fp32, target) batches works; the tensor work runs on the HIP kernels.
+PNG / NIfTI dumps and the medpy metrics of the reference's test() are out of scope.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def getArgs(argv=None):
+    """Same flag names and defaults as trainUMIS.py:35-91, plus --compute_dtype / --world_size."""
+    local_time = time.strftime("%Y-%m-%d %H:%M:%S", time.localtime())
+    p = argparse.ArgumentParser()
+    p.add_argument('--user', default='name of user', type=str)
+    p.add_argument('--experiment', default='UMIS', type=str)
+    p.add_argument('--date', default=local_time.split(' ')[0], type=str)
+    p.add_argument('--start_epoch', type=int, default=1)
+    p.add_argument('--end_epochs', type=int, default=99)
+    p.add_argument('--submission', default='./results', type=str)
+    p.add_argument('--lambda-epochs', type=int, default=50)
+    p.add_argument('--save_freq', default=5, type=int)
+    p.add_argument('--lr', type=float, default=0.002)
+    p.add_argument('--savepath', default='./results/plot/output', type=str)
+    p.add_argument('--save_dir', default='./results', type=str)
+    p.add_argument('--mode', default='train&test', type=str)
+    p.add_argument('--dataset', default='LiTS', type=str)
+    p.add_argument('--folder', default='folder0', type=str)
+    p.add_argument('--input_H', default=240, type=int)
+    p.add_argument('--input_W', default=240, type=int)
+    p.add_argument('--input_D', default=160, type=int)
+    p.add_argument('--crop_H', default=128, type=int)
+    p.add_argument('--crop_W', default=128, type=int)
+    p.add_argument('--crop_D', default=128, type=int)
+    p.add_argument('--output_D', default=155, type=int)
+    p.add_argument('--batch_size', default=8, type=int)
+    p.add_argument('--OOD_Condition', default='normal', type=str)
+    p.add_argument('--OOD_Level', default=1, type=int)
+    p.add_argument('--snapshot', default=True, type=bool)
+    p.add_argument('--Uncertainty_Loss', default=False, type=bool)
+    p.add_argument('--input_modality', default='four', type=str)
+    p.add_argument('--model_name', default='U', type=str)
+    p.add_argument('--test_epoch', type=int, default=199)
+    p.add_argument('--compute_dtype', default='bf16', choices=['bf16', 'fp32'])
+    args = p.parse_args(argv)
+    args.compute_dtype = torch.bfloat16 if args.compute_dtype == 'bf16' else torch.float32
+    apply_dataset_overrides(args)
+    return args
+
+
+def apply_dataset_overrides(args):
+    """Per-dataset settings the reference applies after parsing (trainUMIS.py:1359-1386)."""
+    if args.dataset == 'BraTS':
+        args.batch_size, args.num_classes, args.out_size = 2, 4, (240, 240, 160)
+    elif args.dataset == 'LiTS':
+        args.num_classes = getattr(args, 'num_classes', 3)
+    else:
+        args.num_classes = getattr(args, 'num_classes', 2)
+    return args
+
+
+def adjust_learning_rate(optimizer, epoch, max_epoch, init_lr, power=0.9):
+    # trainUMIS.py:217-219: recomputed from the EPOCH every iteration, rounded to 8 decimals
+    lr = round(init_lr * np.power(1 - (epoch) / max_epoch, power), 8)
+    for group in optimizer.param_groups:
+        group['lr'] = lr
+
+
+class AverageMeter(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def train(args, model, optimizer, epoch, train_loader, reducer=None, log=print):
+    """One epoch; same order of operations as trainUMIS.py:239-263.  `reducer` (devis_amd.parallel)
+    averages gradients across ranks.  The per-iteration loss print is kept (it is a host sync)."""
+    model.train()
+    meter = AverageMeter()
+    step = 0
+    for data in train_loader:
+        adjust_learning_rate(optimizer, epoch, args.end_epochs, args.lr)
+        step += 1
+        x, target = data[0], data[-1]
+        x = x.cuda(non_blocking=True)
+        target = target.cuda(non_blocking=True)
+        args.mode = 'train'
+        evidences, loss = model(x, target, epoch, args.mode, args.dataset)
+        optimizer.zero_grad()
+        loss.requires_grad_(True).backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        optimizer.step()
+        val = loss.item()
+        if log is not None:
+            log("%d,train_loss:%0.3f" % (step, val))
+        meter.update(val)
+    return meter.avg
+
+
+def predict_volume(model, x, dataset, thresholds=()):
+    """The tensor part of val()/test() (trainUMIS.py:283-290, 446-461): evidence -> alpha, S, prob argmax,
+    u = K/S, normalised entropy, u-threshold masks - one fused kernel after the backbone."""
+    model.eval()
+    with torch.no_grad():
+        from .predict import tailor_and_concat
+        logits = tailor_and_concat(x, model.backbone) if dataset == 'BraTS' else model.backbone(x)
+        return ops.evid_infer(logits.contiguous(), False, thresholds, want_evidence=True, want_mne=True)
+
+
+def dice_per_class(pred, target, num_classes):
+    """Foreground dice on device (the reference computes it with numpy after a D2H copy)."""
+    out = []
+    for k in range(1, num_classes):
+        p, t = pred == k, target == k
+        inter = (p & t).sum().double()
+        out.append(((2 * inter) / (p.sum() + t.sum()).clamp_min(1)).item())
+    return out
+
+
+def val(args, model, current_epoch, best_dice, valid_loader, save=True):
+    """trainUMIS.py:265-331: argmax(alpha/S) + dice; checkpoint {'epoch','state_dict'} with the reference's
+    file name and trigger rule (:314-330)."""
+    model.eval()
+    meter = AverageMeter()
+    dice_total = 0.0
+    for data in valid_loader:
+        x, target = data[0].cuda(), data[-1].cuda()
+        if args.dataset == 'BraTS':
+            target = target[..., :155]
+        out = predict_volume(model, x, args.dataset)
+        d = dice_per_class(out["pred"].view(-1), target.reshape(-1), args.num_classes)
+        dice_total += float(np.mean(d))
+    aver_dice = dice_total / max(1, len(valid_loader))
+    if aver_dice > best_dice \
+            or (current_epoch + 1) % int(args.end_epochs - 1) == 0 \
+            or (current_epoch + 1) % int(args.end_epochs - 2) == 0 \
+            or (current_epoch + 1) % int(args.end_epochs - 3) == 0:
+        best_dice = aver_dice
+        if save:
+            tag = '_DUloss' if args.Uncertainty_Loss else ''
+            name = '%s_%s_%s%s_epoch_%d.pth' % (args.model_name, args.dataset, args.folder, tag, current_epoch)
+            os.makedirs(args.save_dir, exist_ok=True)
+            torch.save({'epoch': current_epoch, 'state_dict': model.state_dict()}, os.path.join(args.save_dir, name))
+    return meter.avg, best_dice
