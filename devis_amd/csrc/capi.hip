@@ -6,13 +6,13 @@ namespace devis {
 // conv_direct.hip
 int conv_fwd_direct(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
                     const float*, const void*, void*, hipStream_t);
-int conv_dgrad_direct(const devis_conv_desc*, const void*, const void*, void*, void*, hipStream_t);
+int conv_dgrad_direct(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, hipStream_t);
 int conv_wgrad_direct(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
                       float*, float*, hipStream_t);
 // conv_mfma.hip: return DEVIS_ERR_UNSUPPORTED when the shape is not theirs
 int conv_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
                   const float*, const void*, void*, hipStream_t);
-int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, void*, void*, hipStream_t);
+int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, hipStream_t);
 size_t conv_wgrad_mfma_workspace(const devis_conv_desc*);
 int conv_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
                     float*, float*, void*, size_t, hipStream_t);
@@ -46,13 +46,15 @@ int devis_conv_fwd(const devis_conv_desc* d, const void* x1, const void* x2, con
   return conv_fwd_direct(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
 }
 
-int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, void* dx1, void* dx2, void* stream) {
+int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, const void* w_dgrad,
+                     const void* residual, void* dx1, void* dx2, void* stream) {
   if (!conv_desc_ok(d) || !dy || !w || !dx1) return DEVIS_ERR_BAD_ARG;
   if ((d->C2 > 0) != (dx2 != nullptr)) return DEVIS_ERR_BAD_ARG;
+  if (residual && d->C2 > 0) return DEVIS_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int rc = conv_dgrad_mfma(d, dy, w, dx1, dx2, s);
+  const int rc = conv_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
-  return conv_dgrad_direct(d, dy, w, dx1, dx2, s);
+  return conv_dgrad_direct(d, dy, w, residual, dx1, dx2, s);
 }
 
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d) {

@@ -89,7 +89,7 @@ k_conv_fwd(ConvP p, const T* __restrict__ x1, const T* __restrict__ x2, const T*
 // dA[n, iv, ci] = sum_t sum_co dy[n, ov(iv,t), co] * w[co][t][ci]
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_conv_dgrad(ConvP p, const T* __restrict__ dy, const T* __restrict__ w, T* __restrict__ dx1, T* __restrict__ dx2) {
+k_conv_dgrad(ConvP p, const T* __restrict__ dy, const T* __restrict__ w, const T* __restrict__ res, T* __restrict__ dx1, T* __restrict__ dx2) {
   const int64_t Cin = p.C1 + p.C2;
   const int64_t total = p.N * p.ID * p.IH * p.IW * Cin;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,6 +125,7 @@ k_conv_dgrad(ConvP p, const T* __restrict__ dy, const T* __restrict__ w, T* __re
       }
     }
   }
+  if (res) acc += ld(res + ivf * p.C1 + ci);   // host: residual only when C2 == 0
   if (ci < p.C1) st(dx1 + ivf * p.C1 + ci, acc);
   else st(dx2 + ivf * p.C2 + (ci - p.C1), acc);
 }
@@ -303,10 +304,10 @@ int conv_fwd_direct(const devis_conv_desc* d, const void* x1, const void* x2, co
   return launch_status();
 }
 
-int conv_dgrad_direct(const devis_conv_desc* d, const void* dy, const void* w, void* dx1, void* dx2, hipStream_t s) {
+int conv_dgrad_direct(const devis_conv_desc* d, const void* dy, const void* w, const void* res, void* dx1, void* dx2, hipStream_t s) {
   const ConvP p = to_p(d);
   const int64_t total = p.N * p.ID * p.IH * p.IW * (p.C1 + p.C2);
-  DEVIS_DISPATCH_DTYPE(d->dtype, hipLaunchKernelGGL(k_conv_dgrad<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, p, (const T*)dy, (const T*)w, (T*)dx1, (T*)dx2));
+  DEVIS_DISPATCH_DTYPE(d->dtype, hipLaunchKernelGGL(k_conv_dgrad<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, p, (const T*)dy, (const T*)w, (const T*)res, (T*)dx1, (T*)dx2));
   return launch_status();
 }
 

@@ -1,12 +1,282 @@
-// MFMA implicit-GEMM convolution kernels (bf16, channels-last).  Shapes they do not take
-// return DEVIS_ERR_UNSUPPORTED and the caller routes to the direct kernels.
+// MFMA implicit-GEMM 3x3x3 convolution, bf16 channels-last, gfx950.
+//
+//   out[co][v] = sum_{tap, ci} W[co][tap][ci] * A[v + off(tap)][ci]
+//
+// GEMM orientation: M = cout (A operand = packed weights, k-contiguous rows), N = 16 output
+// voxels along W (B operand = activations), K = (tap, ci).  With v_mfma_f32_16x16x32_bf16 a lane
+// then owns 4 consecutive cout of ONE voxel -> 8-byte coalesced channels-last stores, and the
+// B fragment of a lane is 16 contiguous bytes of one input voxel -> one ds_read_b128.
+// The input halo tile is staged once per ci-chunk through registers into LDS, where the preceding
+// GroupNorm/BatchNorm affine + ReLU is applied on the fly (the normalised tensor never exists in
+// HBM); bias and the residual add run in the epilogue.  Shapes these kernels do not take return
+// DEVIS_ERR_UNSUPPORTED and the caller routes to the direct kernels.
 #include "common.h"
 
 namespace devis {
 
-int conv_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
-                  const float*, const void*, void*, hipStream_t) { return DEVIS_ERR_UNSUPPORTED; }
-int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, void*, void*, hipStream_t) { return DEVIS_ERR_UNSUPPORTED; }
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct Conv3Args {
+  const bf16* x;
+  const bf16* w;      // [Cout][27][Cin]
+  const float* bias;  // [Cout] or null
+  const float* sc;    // [N][Cin] or null
+  const float* sh;
+  const bf16* res;    // like y, or null
+  bf16* y;
+  int N, ID, IH, IW, OD, OH, OW, Cout;
+  int ntd, nth, ntw;
+};
+
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
+  union { bf16 h[2]; unsigned u; } r;
+  r.h[0] = (bf16)a;
+  r.h[1] = (bf16)b;
+  return r.u;
+}
+
+template <int CIN, int COUT_T, int TD, int TH, int TW, int S>
+struct Cfg {
+  static constexpr int CK = CIN >= 32 ? 32 : 16;   // channels per K chunk held in LDS
+  static constexpr int NCH = CIN / CK;
+  static constexpr int MT = COUT_T / 16;
+  static constexpr int NTW = TW / 16;
+  static constexpr int NTB = TD * TH * NTW;         // 16-voxel N tiles per block
+  static constexpr int NT = NTB / 4;                // per wave
+  static constexpr int HD = (TD - 1) * S + 3, HH = (TH - 1) * S + 3, HW = (TW - 1) * S + 3;
+  static constexpr int HV = HD * HH * HW;
+  static constexpr int PITCH = CK * 2;
+  static constexpr int LDS_BYTES = HV * PITCH;
+  static_assert(NTB % 4 == 0, "N tiles must split over 4 waves");
+  static_assert(CIN % CK == 0 && COUT_T % 16 == 0 && TW % 16 == 0, "tile shape");
+};
+
+template <int HH, int HW>
+__device__ __forceinline__ constexpr int tap_off(int t) {
+  return ((t / 9) * HH + (t / 3) % 3) * HW + t % 3;
+}
+
+template <int CIN, int COUT_T, int TD, int TH, int TW, int S, bool PRO>
+__global__ void __launch_bounds__(256)
+k_conv3_mfma(Conv3Args a) {
+  using C = Cfg<CIN, COUT_T, TD, TH, TW, S>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  // XCD-aware (bijective) block -> tile map: blocks b and b+8 share an XCD, give them adjacent tiles
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int twi = tile % a.ntw;
+  const int thi = (tile / a.ntw) % a.nth;
+  const int tdi = (tile / (a.ntw * a.nth)) % a.ntd;
+  const int n = tile / (a.ntw * a.nth * a.ntd);
+  const int od0 = tdi * TD, oh0 = thi * TH, ow0 = twi * TW;
+  const int co_base = blockIdx.y * COUT_T;
+
+  f32x4 acc[C::MT][C::NT];
+#pragma unroll
+  for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane LDS voxel index of each of this wave's N tiles at tap (0,0,0)
+  int ubase[C::NT];
+#pragma unroll
+  for (int j = 0; j < C::NT; ++j) {
+    const int g = wave * C::NT + j;
+    const int ltw = g % C::NTW, lth = (g / C::NTW) % TH, ltd = g / (C::NTW * TH);
+    ubase[j] = ((ltd * S) * C::HH + lth * S) * C::HW + (ltw * 16 + l15) * S;
+  }
+
+  const bf16* wrow = a.w + (size_t)(co_base + l15) * 27 * CIN;
+
+  for (int cc = 0; cc < C::NCH; ++cc) {
+    if (cc > 0) __syncthreads();
+    // ---- stage the halo tile of channels [cc*CK, cc*CK+CK) into LDS (prologue applied, zero padded)
+    {
+      constexpr int PPV = C::CK / 8;      // 16-byte pieces per voxel
+      const int piece = tid % PPV;
+      float scv[8], shv[8];
+      if (PRO) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          scv[j] = a.sc[n * CIN + cc * C::CK + piece * 8 + j];
+          shv[j] = a.sh[n * CIN + cc * C::CK + piece * 8 + j];
+        }
+      }
+      for (int i = tid; i < C::HV * PPV; i += 256) {
+        const int u = i / PPV;
+        const int hw = u % C::HW, hh = (u / C::HW) % C::HH, hd = u / (C::HW * C::HH);
+        const int id = od0 * S - 1 + hd, ih = oh0 * S - 1 + hh, iw = ow0 * S - 1 + hw;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (id >= 0 && id < a.ID && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW) {
+          v = *reinterpret_cast<const uint4*>(a.x + ((size_t)((n * a.ID + id) * a.IH + ih) * a.IW + iw) * CIN + cc * C::CK + piece * 8);
+          if (PRO) {
+            unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float lo = fmaxf(fmaf(bf_lo(wds[j]), scv[2 * j], shv[2 * j]), 0.f);
+              const float hi = fmaxf(fmaf(bf_hi(wds[j]), scv[2 * j + 1], shv[2 * j + 1]), 0.f);
+              wds[j] = pack_bf2(lo, hi);
+            }
+            v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+          }
+        }
+        const int slot = C::CK == 32 ? (piece ^ ((u >> 1) & 3)) : piece;   // XOR swizzle: conflict-free b128 reads
+        *reinterpret_cast<uint4*>(smem + u * C::PITCH + slot * 16) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA over the 27 taps of this channel chunk
+    if (C::CK == 32) {
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        bf16x8 af[C::MT];
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m)
+          af[m] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)m * 16 * 27 * CIN + t * CIN + cc * 32 + lq * 8);
+        const int toff = tap_off<C::HH, C::HW>(t);
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+          const int u = ubase[j] + toff;
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(smem + u * 64 + ((lq ^ ((u >> 1) & 3)) << 4));
+#pragma unroll
+          for (int m = 0; m < C::MT; ++m)
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][j], 0, 0, 0);
+        }
+      }
+    } else {
+      // CK == 16: one K chunk = two taps x 16 channels; lanes 0-31 take tap 2c, lanes 32-63 tap 2c+1
+      const int half = lq & 1, hi = lq >> 1;
+#pragma unroll
+      for (int c = 0; c < 14; ++c) {
+        const int t0 = 2 * c, t1 = 2 * c + 1 < 27 ? 2 * c + 1 : 26;      // phantom tap 27: real data x zero weights
+        bf16x8 af[C::MT];
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+          const bf16* p = wrow + (size_t)m * 16 * 27 * CIN + (t0 + hi) * 16 + half * 8;
+          bf16x8 z;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+          af[m] = (2 * c + hi < 27) ? *reinterpret_cast<const bf16x8*>(p) : z;
+        }
+        const int toff = hi ? tap_off<C::HH, C::HW>(t1) : tap_off<C::HH, C::HW>(t0);
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+          const int u = ubase[j] + toff;
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(smem + u * 32 + half * 16);
+#pragma unroll
+          for (int m = 0; m < C::MT; ++m)
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: + bias (+ residual), 4 consecutive cout of one voxel per lane -> 8-byte stores
+#pragma unroll
+  for (int j = 0; j < C::NT; ++j) {
+    const int g = wave * C::NT + j;
+    const int ltw = g % C::NTW, lth = (g / C::NTW) % TH, ltd = g / (C::NTW * TH);
+    const int od = od0 + ltd, oh = oh0 + lth, ow = ow0 + ltw * 16 + l15;
+    if (od >= a.OD || oh >= a.OH || ow >= a.OW) continue;
+    const size_t vox = (size_t)((n * a.OD + od) * a.OH + oh) * a.OW + ow;
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) {
+      const int co = co_base + m * 16 + lq * 4;
+      float v0 = acc[m][j][0], v1 = acc[m][j][1], v2 = acc[m][j][2], v3 = acc[m][j][3];
+      if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+        v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+      }
+      if (a.res) {
+        const uint2 r = *reinterpret_cast<const uint2*>(a.res + vox * a.Cout + co);
+        v0 += bf_lo(r.x); v1 += bf_hi(r.x); v2 += bf_lo(r.y); v3 += bf_hi(r.y);
+      }
+      uint2 o;
+      o.x = pack_bf2(v0, v1);
+      o.y = pack_bf2(v2, v3);
+      *reinterpret_cast<uint2*>(a.y + vox * a.Cout + co) = o;
+    }
+  }
+}
+
+template <int CIN, int COUT_T, int TD, int TH, int TW, int S>
+static int launch_conv3(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
+                        const float* sh, const void* res, void* y, hipStream_t s) {
+  using C = Cfg<CIN, COUT_T, TD, TH, TW, S>;
+  Conv3Args a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.sc = sc; a.sh = sh; a.res = (const bf16*)res; a.y = (bf16*)y;
+  a.N = (int)d->N; a.ID = (int)d->ID; a.IH = (int)d->IH; a.IW = (int)d->IW;
+  a.OD = (int)d->OD; a.OH = (int)d->OH; a.OW = (int)d->OW; a.Cout = (int)d->Cout;
+  a.ntd = (int)cdiv(d->OD, TD); a.nth = (int)cdiv(d->OH, TH); a.ntw = (int)cdiv(d->OW, TW);
+  const int64_t tiles = (int64_t)a.N * a.ntd * a.nth * a.ntw;
+  if (tiles > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)tiles, (unsigned)(d->Cout / COUT_T));
+  if (sc) {
+    auto k = k_conv3_mfma<CIN, COUT_T, TD, TH, TW, S, true>;
+    if (C::LDS_BYTES > 65536) {
+      static bool once = false;
+      if (!once) { if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES))) return DEVIS_ERR_HIP; once = true; }
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), C::LDS_BYTES, s, a);
+  } else {
+    auto k = k_conv3_mfma<CIN, COUT_T, TD, TH, TW, S, false>;
+    if (C::LDS_BYTES > 65536) {
+      static bool once = false;
+      if (!once) { if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES))) return DEVIS_ERR_HIP; once = true; }
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), C::LDS_BYTES, s, a);
+  }
+  return launch_status();
+}
+
+static bool is_3x3x3(const devis_conv_desc* d) {
+  return d->KD == 3 && d->KH == 3 && d->KW == 3 && d->PD == 1 && d->PH == 1 && d->PW == 1 && d->SD == d->SH && d->SH == d->SW;
+}
+static bool fits_int(const devis_conv_desc* d) {
+  const int64_t big = d->N * d->ID * d->IH * d->IW * (d->C1 + d->C2);
+  const int64_t bigo = d->N * d->OD * d->OH * d->OW * d->Cout;
+  return big < (int64_t)1 << 40 && bigo < (int64_t)1 << 40 && d->N * d->ID * d->IH * d->IW < 0x7fffffff;
+}
+
+int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                  const float* sc, const float* sh, const void* res, void* y, hipStream_t s) {
+  if (d->dtype != DEVIS_BF16 || d->C2 != 0 || x2 || !is_3x3x3(d) || !fits_int(d)) return DEVIS_ERR_UNSUPPORTED;
+  const int ci = (int)d->C1, co = (int)d->Cout, st = d->SD;
+  if (st == 1) {
+    if (ci == 16 && co == 16) return launch_conv3<16, 16, 8, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
+    if (ci == 32 && co == 32) return launch_conv3<32, 32, 4, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
+    if (ci == 64 && co == 64) return launch_conv3<64, 64, 4, 4, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
+    if (ci == 128 && co == 128) return launch_conv3<128, 64, 2, 4, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
+    // transposed channel counts (dgrad of the stride-2 layers is not here; these serve generic use)
+  } else if (st == 2) {
+    if (ci == 16 && co == 32) return launch_conv3<16, 32, 2, 4, 16, 2>(d, x1, w, bias, sc, sh, res, y, s);
+    if (ci == 32 && co == 64) return launch_conv3<32, 64, 2, 2, 16, 2>(d, x1, w, bias, sc, sh, res, y, s);
+    if (ci == 64 && co == 128) return launch_conv3<64, 64, 2, 2, 16, 2>(d, x1, w, bias, sc, sh, res, y, s);
+  }
+  return DEVIS_ERR_UNSUPPORTED;
+}
+
+// dgrad of a stride-1 3x3x3 conv = the same conv with flipped taps and swapped channel roles:
+// w_dgrad is [Cin][27][Cout] with tap t' = 26 - t (devis_pack_conv_weight_dgrad).
+int conv_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_dgrad, const void* res, void* dx1, void* dx2, hipStream_t s) {
+  if (!w_dgrad || d->dtype != DEVIS_BF16 || d->C2 != 0 || dx2 || !is_3x3x3(d) || d->SD != 1 || !fits_int(d)) return DEVIS_ERR_UNSUPPORTED;
+  devis_conv_desc t = *d;
+  t.C1 = d->Cout; t.Cout = d->C1;
+  t.ID = d->OD; t.IH = d->OH; t.IW = d->OW; t.OD = d->ID; t.OH = d->IH; t.OW = d->IW;
+  return conv_fwd_mfma(&t, dy, nullptr, w_dgrad, nullptr, nullptr, nullptr, res, dx1, s);
+}
+
 size_t conv_wgrad_mfma_workspace(const devis_conv_desc*) { return 0; }
 int conv_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
                     float*, float*, void*, size_t, hipStream_t) { return DEVIS_ERR_UNSUPPORTED; }

@@ -43,6 +43,15 @@ __global__ void k_pack_convT(const float* __restrict__ src, T* __restrict__ dst,
   st(dst + i, src[(ci * Cout + co) * Tn + t]);
 }
 
+// dst[ci][T-1-t][co] = src[co][t][ci]   (forward-packed -> dgrad-packed, taps flipped)
+template <typename T>
+__global__ void k_repack_dgrad(const T* __restrict__ src, T* __restrict__ dst, int64_t Cout, int64_t Cin, int64_t Tn) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * Cin * Tn) return;
+  const int64_t co = i % Cout, tf = (i / Cout) % Tn, ci = i / (Cout * Tn);
+  dst[i] = src[(co * Tn + (Tn - 1 - tf)) * Cin + ci];
+}
+
 }  // namespace devis
 
 using namespace devis;
@@ -75,6 +84,13 @@ int devis_pack_convT_weight(const float* w, void* dst, int64_t Cin, int64_t Cout
   if (!w || !dst || Cout <= 0 || Cin <= 0 || Tn <= 0) return DEVIS_ERR_BAD_ARG;
   const int64_t n = Cout * Cin * Tn;
   DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_convT<T>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (T*)dst, Cin, Cout, Tn));
+  return launch_status();
+}
+
+int devis_repack_conv_weight_dgrad(const void* w_packed, void* dst, int64_t Cout, int64_t Cin, int64_t Tn, int dtype, void* stream) {
+  if (!w_packed || !dst || Cout <= 0 || Cin <= 0 || Tn <= 0) return DEVIS_ERR_BAD_ARG;
+  const int64_t n = Cout * Cin * Tn;
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_repack_dgrad<T>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)w_packed, (T*)dst, Cout, Cin, Tn));
   return launch_status();
 }
 

@@ -168,7 +168,7 @@ def conv_fwd(x1: Tensor, x2: Optional[Tensor], wp: Tensor, bias: Optional[Tensor
     return y
 
 
-def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0):
+def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, residual: Optional[Tensor] = None):
     """-> (dx1, dx2|None): gradient w.r.t. the conv's (post-prologue) inputs."""
     _need_cuda(dy, wp)
     n = in_shape1[0]
@@ -179,7 +179,16 @@ def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0):
         raise _lib.DevisError("dgrad: dy shape %s inconsistent with the layer" % (tuple(dy.shape),))
     dx1 = torch.empty(tuple(in_shape1), dtype=dy.dtype, device=dy.device)
     dx2 = torch.empty(tuple(in_shape1[:-1]) + (c2,), dtype=dy.dtype, device=dy.device) if c2 else None
-    check(_lib.load().devis_conv_dgrad(C.byref(d), _p(dy), _p(wp), _p(dx1), _p(dx2), _stream()), "conv_dgrad")
+    lib = _lib.load()
+    wd = None
+    if dy.dtype == torch.bfloat16 and c2 == 0 and geom.k == (3, 3, 3) and geom.s == (1, 1, 1):
+        # tap-flipped [Cin][T][Cout] packing: dgrad runs on the MFMA forward kernel
+        wd = torch.empty((wp.shape[2], wp.shape[1], wp.shape[0]), dtype=wp.dtype, device=wp.device)
+        check(lib.devis_repack_conv_weight_dgrad(_p(wp), _p(wd), wp.shape[0], wp.shape[2], wp.shape[1],
+                                                 dt_code(wp.dtype), _stream()), "repack_conv_weight_dgrad")
+    if residual is not None and (c2 or residual.shape != dx1.shape):
+        raise _lib.DevisError("dgrad residual needs C2 == 0 and the input's shape")
+    check(lib.devis_conv_dgrad(C.byref(d), _p(dy), _p(wp), _p(wd), _p(residual), _p(dx1), _p(dx2), _stream()), "conv_dgrad")
     return dx1, dx2
 
 

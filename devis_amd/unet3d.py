@@ -149,11 +149,11 @@ class _Run:
         return self.conv("endconv", h, G1)
 
     # ---- backward blocks
-    def _conv_bwd(self, e, dy, need_dx=True):
+    def _conv_bwd(self, e, dy, need_dx=True, skip=None):
         _, name, x, wp, geom = e
         g = self.grads
         g[name + ".weight"], g[name + ".bias"] = ops.conv_wgrad(x, None, dy, geom, self.P[name + ".weight"].shape)
-        return ops.conv_dgrad(dy, wp, geom, x.shape)[0] if need_dx else None
+        return ops.conv_dgrad(dy, wp, geom, x.shape, residual=skip)[0] if need_dx else None
 
     def _en_bwd(self, e, dout):
         _, name, x, h, st1, st2, w1, w2 = e
@@ -182,7 +182,7 @@ class _Run:
             da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, True)
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
             x, None, dh1, G3, P[name + ".conv1.weight"].shape)
-        return ops.add(ops.conv_dgrad(dh1, w1, G3, x.shape)[0], dout)
+        return ops.conv_dgrad(dh1, w1, G3, x.shape, residual=dout)[0]
 
     def _up_bwd(self, e, dy):
         _, name, x, prev, t, up, w1, wt, w3 = e
@@ -208,11 +208,11 @@ class _Run:
         d = self._de_bwd(pop(), d); d, ds3 = self._up_bwd(pop(), d)   # DeBlock4, DeUpCat4
         for _ in range(4):
             d = self._en_bwd(pop(), d)                           # EnBlock4_4..1
-        d = ops.add(self._conv_bwd(pop(), d), ds3)               # EnDown3 (+ skip gradient)
+        d = self._conv_bwd(pop(), d, skip=ds3)               # EnDown3 (+ skip gradient)
         d = self._en_bwd(pop(), d); d = self._en_bwd(pop(), d)
-        d = ops.add(self._conv_bwd(pop(), d), ds2)               # EnDown2
+        d = self._conv_bwd(pop(), d, skip=ds2)               # EnDown2
         d = self._en_bwd(pop(), d); d = self._en_bwd(pop(), d)
-        d = ops.add(self._conv_bwd(pop(), d), ds1)               # EnDown1
+        d = self._conv_bwd(pop(), d, skip=ds1)               # EnDown1
         d = self._en_bwd(pop(), d)                               # EnBlock1
         return self._conv_bwd(pop(), d, need_dx)                 # InitConv
 

@@ -82,8 +82,13 @@ int devis_conv_fwd(const devis_conv_desc* d, const void* x1, const void* x2, con
 /* dA = conv_transpose(dy, w): gradient w.r.t. the conv's (post-prologue) input,
  * split over the two virtual-concat inputs (dx2 may be NULL when C2 = 0).
  * Replaces cuDNN dgrad of the same layers. */
-int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w_packed,
-                     void* dx1, void* dx2, void* stream);
+/* w_dgrad: optional [Cin][T][Cout] tap-flipped packing (devis_repack_conv_weight_dgrad) that lets the
+ * stride-1 3x3x3 layers run dgrad on the MFMA forward kernel; residual: optional tensor added to dx1
+ * (skip-connection gradient, only when C2 == 0). */
+int devis_repack_conv_weight_dgrad(const void* w_packed, void* dst, int64_t Cout, int64_t Cin, int64_t T,
+                                   int dtype, void* stream);
+int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w_packed, const void* w_dgrad,
+                     const void* residual, void* dx1, void* dx2, void* stream);
 /* dw [Cout][C1+C2][T] fp32 (PyTorch layout) and dbias [Cout] fp32 (may be NULL).
  * The conv input is recomputed from x1/x2 with the same prologue. */
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d);

@@ -32,6 +32,17 @@ CONV_CASES = [
     (2, 16, 0, 4, (4, 4, 6), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (2, 8, 24, 16, (9, 11), (3, 3), (1, 1), (1, 1)),
     (3, 3, 0, 32, (12, 7), (3, 3), (1, 1), (1, 1)),
+    # shapes the MFMA implicit-GEMM kernels take in bf16 (incl. ragged tiles and stride 2)
+    (2, 16, 0, 16, (8, 8, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 16, 0, 16, (6, 10, 20), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 32, 0, 32, (8, 8, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 32, 0, 32, (5, 9, 24), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 64, 0, 64, (4, 8, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 128, 0, 128, (4, 4, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 128, 0, 128, (2, 2, 2), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 16, 0, 32, (8, 8, 32), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (2, 32, 0, 64, (8, 8, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (1, 64, 0, 128, (4, 8, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
 ]
 
 
