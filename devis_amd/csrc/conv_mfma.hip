@@ -11,11 +11,9 @@
 // HBM); bias and the residual add run in the epilogue.  Shapes these kernels do not take return
 // DEVIS_ERR_UNSUPPORTED and the caller routes to the direct kernels.
 #include "common.h"
+#include "mfma_common.h"
 
 namespace devis {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct Conv3Args {
   const bf16* x;
@@ -28,15 +26,6 @@ struct Conv3Args {
   int N, ID, IH, IW, OD, OH, OW, Cout;
   int ntd, nth, ntw;
 };
-
-__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
-  union { bf16 h[2]; unsigned u; } r;
-  r.h[0] = (bf16)a;
-  r.h[1] = (bf16)b;
-  return r.u;
-}
 
 template <int CIN, int COUT_T, int TD, int TH, int TW, int S>
 struct Cfg {
@@ -276,9 +265,5 @@ int conv_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_dgra
   t.ID = d->OD; t.IH = d->OH; t.IW = d->OW; t.OD = d->ID; t.OH = d->IH; t.OW = d->IW;
   return conv_fwd_mfma(&t, dy, nullptr, w_dgrad, nullptr, nullptr, nullptr, res, dx1, s);
 }
-
-size_t conv_wgrad_mfma_workspace(const devis_conv_desc*) { return 0; }
-int conv_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
-                    float*, float*, void*, size_t, hipStream_t) { return DEVIS_ERR_UNSUPPORTED; }
 
 }  // namespace devis
