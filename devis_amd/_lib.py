@@ -58,7 +58,7 @@ SIGNATURES = {
     "devis_conv_wgrad_workspace_bytes": (_SZ, [_CD]),
     "devis_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "devis_convT_fwd": (_I, [_CTD, _P, _P, _P, _P, _P]),
-    "devis_convT_dgrad": (_I, [_CTD, _P, _P, _P, _P]),
+    "devis_convT_dgrad": (_I, [_CTD, _P, _P, _P, _P, _P]),
     "devis_convT_wgrad_workspace_bytes": (_SZ, [_CTD]),
     "devis_convT_wgrad": (_I, [_CTD, _P, _P, _P, _P, _P, _SZ, _P]),
     "devis_moments_workspace_bytes": (_SZ, [_I64, _I64, _I64]),

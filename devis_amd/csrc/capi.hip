@@ -13,6 +13,12 @@ int conv_wgrad_direct(const devis_conv_desc*, const void*, const void*, const fl
 int conv_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
                   const float*, const void*, void*, hipStream_t);
 int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, hipStream_t);
+// pointwise_mfma.hip
+int conv1_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const void*, void*, hipStream_t);
+int conv1_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, hipStream_t);
+int conv3s2_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
+size_t conv1_wgrad_mfma_workspace(const devis_conv_desc*);
+int conv1_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, float*, float*, void*, size_t, hipStream_t);
 size_t conv_wgrad_mfma_workspace(const devis_conv_desc*);
 int conv_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
                     float*, float*, void*, size_t, hipStream_t);
@@ -41,8 +47,12 @@ int devis_conv_fwd(const devis_conv_desc* d, const void* x1, const void* x2, con
   if ((d->C2 > 0) != (x2 != nullptr)) return DEVIS_ERR_BAD_ARG;
   if ((in_scale != nullptr) != (in_shift != nullptr)) return DEVIS_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int rc = conv_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
+  int rc = conv_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  if (!in_scale) {
+    rc = conv1_fwd_mfma(d, x1, x2, w, bias, residual, y, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  }
   return conv_fwd_direct(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
 }
 
@@ -52,14 +62,19 @@ int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, co
   if ((d->C2 > 0) != (dx2 != nullptr)) return DEVIS_ERR_BAD_ARG;
   if (residual && d->C2 > 0) return DEVIS_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int rc = conv_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, s);
+  int rc = conv_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = conv1_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = conv3s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   return conv_dgrad_direct(d, dy, w, residual, dx1, dx2, s);
 }
 
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d) {
   if (!conv_desc_ok(d)) return 0;
-  return conv_wgrad_mfma_workspace(d);
+  const size_t a = conv_wgrad_mfma_workspace(d), b = conv1_wgrad_mfma_workspace(d);
+  return a > b ? a : b;
 }
 
 int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, const float* in_scale,
@@ -69,8 +84,12 @@ int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, c
   if ((d->C2 > 0) != (x2 != nullptr)) return DEVIS_ERR_BAD_ARG;
   if ((in_scale != nullptr) != (in_shift != nullptr)) return DEVIS_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int rc = conv_wgrad_mfma(d, x1, x2, in_scale, in_shift, dy, dw, dbias, ws, ws_bytes, s);
+  int rc = conv_wgrad_mfma(d, x1, x2, in_scale, in_shift, dy, dw, dbias, ws, ws_bytes, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  if (!in_scale) {
+    rc = conv1_wgrad_mfma(d, x1, x2, dy, dw, dbias, ws, ws_bytes, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  }
   return conv_wgrad_direct(d, x1, x2, in_scale, in_shift, dy, dw, dbias, s);
 }
 

@@ -273,6 +273,12 @@ k_convT_wgrad(ConvTP p, const T* __restrict__ x, const T* __restrict__ dy, float
   atomicAdd(dw + (ci * p.Cout + co) * Tn + t, acc);
 }
 
+int convT_fwd_mfma(const devis_convT_desc*, const void*, const void*, const float*, void*, hipStream_t);
+int convT_dgrad_mfma(const devis_convT_desc*, const void*, const void*, void*, hipStream_t);
+
+size_t convT_wgrad_mfma_workspace(const devis_convT_desc*);
+int convT_wgrad_mfma(const devis_convT_desc*, const void*, const void*, float*, float*, void*, size_t, hipStream_t);
+
 static inline bool descT_ok(const devis_convT_desc* d) {
   if (!d || d->N <= 0 || d->ID <= 0 || d->IH <= 0 || d->IW <= 0 || d->Cin <= 0 || d->Cout <= 0) return false;
   if (d->KD < 1 || d->KD > 2 || d->KH < 1 || d->KH > 2 || d->KW < 1 || d->KW > 2) return false;
@@ -340,26 +346,37 @@ extern "C" {
 
 int devis_convT_fwd(const devis_convT_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream) {
   if (!descT_ok(d) || !x || !w || !y) return DEVIS_ERR_BAD_ARG;
+  {
+    const int rc = convT_fwd_mfma(d, x, w, bias, y, (hipStream_t)stream);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  }
   const ConvTP p = to_tp(d);
   const int64_t total = p.N * p.ID * p.KD * p.IH * p.KH * p.IW * p.KW * p.Cout;
   DEVIS_DISPATCH_DTYPE(d->dtype, hipLaunchKernelGGL(k_convT_fwd<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p, (const T*)x, (const T*)w, bias, (T*)y));
   return launch_status();
 }
 
-int devis_convT_dgrad(const devis_convT_desc* d, const void* dy, const void* w, void* dx, void* stream) {
+int devis_convT_dgrad(const devis_convT_desc* d, const void* dy, const void* w, const void* w_t, void* dx, void* stream) {
   if (!descT_ok(d) || !dy || !w || !dx) return DEVIS_ERR_BAD_ARG;
+  {
+    const int rc = convT_dgrad_mfma(d, dy, w_t, dx, (hipStream_t)stream);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  }
   const ConvTP p = to_tp(d);
   const int64_t total = p.N * p.ID * p.IH * p.IW * p.Cin;
   DEVIS_DISPATCH_DTYPE(d->dtype, hipLaunchKernelGGL(k_convT_dgrad<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p, (const T*)dy, (const T*)w, (T*)dx));
   return launch_status();
 }
 
-size_t devis_convT_wgrad_workspace_bytes(const devis_convT_desc* d) { (void)d; return 0; }
+size_t devis_convT_wgrad_workspace_bytes(const devis_convT_desc* d) { return descT_ok(d) ? convT_wgrad_mfma_workspace(d) : 0; }
 
 int devis_convT_wgrad(const devis_convT_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                       void* workspace, size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
   if (!descT_ok(d) || !x || !dy || !dw) return DEVIS_ERR_BAD_ARG;
+  {
+    const int rc = convT_wgrad_mfma(d, x, dy, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  }
   const ConvTP p = to_tp(d);
   hipStream_t s = (hipStream_t)stream;
   const int Tn = p.KD * p.KH * p.KW;

@@ -1,0 +1,259 @@
+// MFMA "gather-GEMM" for the layers without a spatial halo (bf16 channels-last, gfx950):
+//   1x1 conv forward (virtual concat of two inputs) and its dgrad (two outputs),
+//   ConvTranspose k2s2 forward (scatter store) and dgrad (gather over the 2x2x2 taps),
+//   dgrad of the stride-2 3x3x3 convs (one GEMM per output-parity class, 1/2/4/8 taps).
+// out[m][v] = sum_k A[m][k] * B[k][v]: M = output channels (x taps for ConvT fwd), N = 16 voxels along W,
+// K = source channels (x taps).  B fragments are 16-byte global loads (every source byte is used once, so
+// there is nothing to stage in LDS); A fragments (weights) come from L1/L2.  These layers are HBM-bound.
+#include "common.h"
+#include "mfma_common.h"
+
+namespace devis {
+
+enum { PW_CONV1 = 0, PW_CONVT_FWD = 1, PW_CONVT_DGRAD = 2, PW_S2_DGRAD = 3 };
+
+struct PwArgs {
+  const bf16* x1; const bf16* x2; const bf16* w; const float* bias; const bf16* res;
+  bf16* y1; bf16* y2;
+  int C1, C2, K, M, M1;
+  int N, D, H, W;        // voxel grid the N dimension runs over
+  int Cs;                // channels per tap of the gathered tensor (ConvT dgrad / s2 dgrad: Cout; ConvT fwd: Cout)
+  int KD, KH, KW;        // ConvT kernel (1 or 2 per dim)
+  int OD, OH, OW;        // s2 dgrad: coarse (dy) grid;  ConvT: fine (output) grid
+  int ntw;               // 16-voxel tiles per row
+  int64_t ntiles;
+};
+
+template <int MODE>
+__device__ __forceinline__ uint4 pw_load_b(const PwArgs& a, int k0, int n, int d, int h, int w, bool vox_ok, int cls) {
+  uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  if (!vox_ok || k0 >= a.K) return z;
+  if (MODE == PW_CONV1 || MODE == PW_CONVT_FWD) {
+    const size_t v = ((size_t)(n * a.D + d) * a.H + h) * a.W + w;
+    if (k0 < a.C1) return *reinterpret_cast<const uint4*>(a.x1 + v * a.C1 + k0);
+    return *reinterpret_cast<const uint4*>(a.x2 + v * a.C2 + (k0 - a.C1));
+  } else if (MODE == PW_CONVT_DGRAD) {
+    const int p = k0 / a.Cs, c = k0 % a.Cs;
+    const int pw = p % a.KW, ph = (p / a.KW) % a.KH, pd = p / (a.KW * a.KH);
+    const size_t ov = ((size_t)(n * a.OD + d * a.KD + pd) * a.OH + h * a.KH + ph) * a.OW + w * a.KW + pw;
+    return *reinterpret_cast<const uint4*>(a.x1 + ov * a.Cs + c);
+  } else {   // PW_S2_DGRAD: (d,h,w) are class coordinates, fine voxel = 2*j + parity
+    const int tj = k0 / a.Cs, c = k0 % a.Cs;
+    const int bw = cls & 1, bh = (cls >> 1) & 1, bd = (cls >> 2) & 1;
+    // per odd dim one bit of tj picks kd in {0,2} (0 -> kd=0 -> coarse j+1 ; 1 -> kd=2 -> coarse j); even dim: kd=1 -> j
+    int bit = 0;
+    const int sw = bw ? ((tj >> bit++) & 1) : -1;
+    const int sh = bh ? ((tj >> bit++) & 1) : -1;
+    const int sd = bd ? ((tj >> bit++) & 1) : -1;
+    const int ow = (sw == 0) ? w + 1 : w, oh = (sh == 0) ? h + 1 : h, od = (sd == 0) ? d + 1 : d;
+    if (ow >= a.OW || oh >= a.OH || od >= a.OD) return z;
+    const size_t ov = ((size_t)(n * a.OD + od) * a.OH + oh) * a.OW + ow;
+    return *reinterpret_cast<const uint4*>(a.x1 + ov * a.Cs + c);
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ uint4 pw_load_a(const PwArgs& a, int m, int k0, int cls) {
+  uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  if (m >= a.M || k0 >= a.K) return z;
+  if (MODE != PW_S2_DGRAD) return *reinterpret_cast<const uint4*>(a.w + (size_t)m * a.K + k0);
+  const int tj = k0 / a.Cs, c = k0 % a.Cs;
+  const int bw = cls & 1, bh = (cls >> 1) & 1, bd = (cls >> 2) & 1;
+  int bit = 0;
+  const int kw = bw ? 2 * ((tj >> bit++) & 1) : 1;
+  const int kh = bh ? 2 * ((tj >> bit++) & 1) : 1;
+  const int kd = bd ? 2 * ((tj >> bit++) & 1) : 1;
+  const int t = (kd * 3 + kh) * 3 + kw;
+  return *reinterpret_cast<const uint4*>(a.w + ((size_t)m * 27 + (26 - t)) * a.Cs + c);   // tap-flipped dgrad packing
+}
+
+template <int MODE, int MTP, int NT>
+__global__ void __launch_bounds__(256)
+k_pw_mfma(PwArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int cls = MODE == PW_S2_DGRAD ? (int)blockIdx.y : 0;
+  int K = a.K;
+  if (MODE == PW_S2_DGRAD) K = a.Cs << (((cls >> 0) & 1) + ((cls >> 1) & 1) + ((cls >> 2) & 1));
+  PwArgs b = a;
+  b.K = K;
+  const int kchunks = (K + 31) >> 5;
+
+  int nn[NT], dd[NT], hh[NT], ww[NT];
+  bool ok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int64_t tile = ((int64_t)blockIdx.x * 4 + wave) * NT + j;
+    const bool tv = tile < a.ntiles;
+    const int64_t tt = tv ? tile : 0;
+    const int twi = (int)(tt % a.ntw);
+    int64_t r = tt / a.ntw;
+    hh[j] = (int)(r % a.H); r /= a.H;
+    dd[j] = (int)(r % a.D);
+    nn[j] = (int)(r / a.D);
+    ww[j] = twi * 16 + l15;
+    ok[j] = tv && ww[j] < a.W;
+  }
+
+  for (int m0 = 0; m0 < a.M; m0 += MTP * 16) {
+    f32x4 acc[MTP][NT];
+#pragma unroll
+    for (int m = 0; m < MTP; ++m)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < kchunks; ++kc) {
+      const int k0 = kc * 32 + lq * 8;
+      union { uint4 u; bf16x8 v; } af[MTP], bf[NT];
+#pragma unroll
+      for (int m = 0; m < MTP; ++m) af[m].u = pw_load_a<MODE>(b, m0 + m * 16 + l15, k0, cls);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j].u = pw_load_b<MODE>(b, k0, nn[j], dd[j], hh[j], ww[j], ok[j], cls);
+#pragma unroll
+      for (int m = 0; m < MTP; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m].v, bf[j].v, acc[m][j], 0, 0, 0);
+    }
+    // epilogue: lane owns rows mrow..mrow+3 of voxel l15
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (!ok[j]) continue;
+#pragma unroll
+      for (int m = 0; m < MTP; ++m) {
+        const int mrow = m0 + m * 16 + lq * 4;
+        if (mrow >= a.M) continue;
+        float v0 = acc[m][j][0], v1 = acc[m][j][1], v2 = acc[m][j][2], v3 = acc[m][j][3];
+        bf16* dst;
+        int brow = mrow;
+        if (MODE == PW_CONV1) {
+          const size_t v = ((size_t)(nn[j] * a.D + dd[j]) * a.H + hh[j]) * a.W + ww[j];
+          dst = mrow < a.M1 ? a.y1 + v * a.M1 + mrow : a.y2 + v * (a.M - a.M1) + (mrow - a.M1);
+          if (a.res) {
+            const uint2 r = *reinterpret_cast<const uint2*>(a.res + v * a.M1 + mrow);
+            v0 += bf_lo(r.x); v1 += bf_hi(r.x); v2 += bf_lo(r.y); v3 += bf_hi(r.y);
+          }
+        } else if (MODE == PW_CONVT_FWD) {
+          const int p = mrow / a.Cs, c = mrow % a.Cs;
+          const int pw = p % a.KW, ph = (p / a.KW) % a.KH, pd = p / (a.KW * a.KH);
+          const size_t ov = ((size_t)(nn[j] * a.OD + dd[j] * a.KD + pd) * a.OH + hh[j] * a.KH + ph) * a.OW + ww[j] * a.KW + pw;
+          dst = a.y1 + ov * a.Cs + c;
+          brow = c;
+        } else if (MODE == PW_CONVT_DGRAD) {
+          const size_t v = ((size_t)(nn[j] * a.D + dd[j]) * a.H + hh[j]) * a.W + ww[j];
+          dst = a.y1 + v * a.M + mrow;
+        } else {
+          const int fw = 2 * ww[j] + (cls & 1), fh = 2 * hh[j] + ((cls >> 1) & 1), fd = 2 * dd[j] + ((cls >> 2) & 1);
+          const size_t v = ((size_t)(nn[j] * (2 * a.D) + fd) * (2 * a.H) + fh) * (2 * a.W) + fw;
+          dst = a.y1 + v * a.M + mrow;
+          if (a.res) {
+            const uint2 r = *reinterpret_cast<const uint2*>(a.res + v * a.M + mrow);
+            v0 += bf_lo(r.x); v1 += bf_hi(r.x); v2 += bf_lo(r.y); v3 += bf_hi(r.y);
+          }
+        }
+        if (a.bias) {
+          const float4 bb = *reinterpret_cast<const float4*>(a.bias + brow);
+          v0 += bb.x; v1 += bb.y; v2 += bb.z; v3 += bb.w;
+        }
+        uint2 o;
+        o.x = pack_bf2(v0, v1);
+        o.y = pack_bf2(v2, v3);
+        *reinterpret_cast<uint2*>(dst) = o;
+      }
+    }
+  }
+}
+
+template <int MODE>
+static int pw_launch(PwArgs& a, int ngrid_y, hipStream_t s) {
+  a.ntw = (int)cdiv(a.W, 16);
+  a.ntiles = (int64_t)a.N * a.D * a.H * a.ntw;
+  const int mt = (int)cdiv(a.M, 16);
+  if (mt >= 4) {
+    const dim3 grid((unsigned)cdiv(a.ntiles, 4 * 2), (unsigned)ngrid_y);
+    hipLaunchKernelGGL((k_pw_mfma<MODE, 4, 2>), grid, dim3(256), 0, s, a);
+  } else if (mt >= 2) {
+    const dim3 grid((unsigned)cdiv(a.ntiles, 4 * 4), (unsigned)ngrid_y);
+    hipLaunchKernelGGL((k_pw_mfma<MODE, 2, 4>), grid, dim3(256), 0, s, a);
+  } else {
+    const dim3 grid((unsigned)cdiv(a.ntiles, 4 * 4), (unsigned)ngrid_y);
+    hipLaunchKernelGGL((k_pw_mfma<MODE, 1, 4>), grid, dim3(256), 0, s, a);
+  }
+  return launch_status();
+}
+
+static bool small_enough(int64_t v) { return v > 0 && v < 0x7fffffff; }
+
+// ---- 1x1 conv forward: y = W x (+bias, +residual), x = virtual cat(x1, x2)
+int conv1_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                   const void* res, void* y, hipStream_t s) {
+  if (d->dtype != DEVIS_BF16 || d->KD != 1 || d->KH != 1 || d->KW != 1 || d->SD != 1 || d->SH != 1 || d->SW != 1) return DEVIS_ERR_UNSUPPORTED;
+  if (d->PD || d->PH || d->PW) return DEVIS_ERR_UNSUPPORTED;
+  if (d->C1 % 8 || d->C2 % 8 || d->Cout % 4) return DEVIS_ERR_UNSUPPORTED;
+  if (!small_enough(d->N * d->ID * d->IH * d->IW)) return DEVIS_ERR_UNSUPPORTED;
+  PwArgs a = {};
+  a.x1 = (const bf16*)x1; a.x2 = (const bf16*)x2; a.w = (const bf16*)w; a.bias = bias; a.res = (const bf16*)res;
+  a.y1 = (bf16*)y; a.y2 = nullptr;
+  a.C1 = (int)d->C1; a.C2 = (int)d->C2; a.K = a.C1 + a.C2; a.M = (int)d->Cout; a.M1 = a.M;
+  a.N = (int)d->N; a.D = (int)d->ID; a.H = (int)d->IH; a.W = (int)d->IW;
+  return pw_launch<PW_CONV1>(a, 1, s);
+}
+
+// ---- 1x1 conv dgrad: (dx1, dx2) = W^T dy; w_t is [Cin][Cout] (devis_repack_conv_weight_dgrad with T = 1)
+int conv1_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_t, const void* res, void* dx1, void* dx2,
+                     hipStream_t s) {
+  if (!w_t || d->dtype != DEVIS_BF16 || d->KD != 1 || d->KH != 1 || d->KW != 1 || d->SD != 1 || d->SH != 1 || d->SW != 1) return DEVIS_ERR_UNSUPPORTED;
+  if (d->PD || d->PH || d->PW) return DEVIS_ERR_UNSUPPORTED;
+  if (d->Cout % 8 || d->C1 % 16 || d->C2 % 4) return DEVIS_ERR_UNSUPPORTED;    // M tiles must not straddle dx1/dx2
+  if (!small_enough(d->N * d->ID * d->IH * d->IW)) return DEVIS_ERR_UNSUPPORTED;
+  PwArgs a = {};
+  a.x1 = (const bf16*)dy; a.w = (const bf16*)w_t; a.res = (const bf16*)res;
+  a.y1 = (bf16*)dx1; a.y2 = (bf16*)dx2;
+  a.C1 = (int)d->Cout; a.C2 = 0; a.K = a.C1; a.M = (int)(d->C1 + d->C2); a.M1 = (int)d->C1;
+  a.N = (int)d->N; a.D = (int)d->ID; a.H = (int)d->IH; a.W = (int)d->IW;
+  return pw_launch<PW_CONV1>(a, 1, s);
+}
+
+// ---- dgrad of a stride-2 3x3x3 conv (even input sizes); w_dgrad = tap-flipped [Cin][27][Cout]
+int conv3s2_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_dgrad, const void* res, void* dx,
+                       hipStream_t s) {
+  if (!w_dgrad || d->dtype != DEVIS_BF16 || d->C2 != 0) return DEVIS_ERR_UNSUPPORTED;
+  if (!(d->KD == 3 && d->KH == 3 && d->KW == 3 && d->PD == 1 && d->PH == 1 && d->PW == 1 && d->SD == 2 && d->SH == 2 && d->SW == 2)) return DEVIS_ERR_UNSUPPORTED;
+  if ((d->ID | d->IH | d->IW) & 1) return DEVIS_ERR_UNSUPPORTED;
+  if (d->Cout % 8 || d->C1 % 4) return DEVIS_ERR_UNSUPPORTED;
+  if (!small_enough(d->N * d->ID * d->IH * d->IW)) return DEVIS_ERR_UNSUPPORTED;
+  PwArgs a = {};
+  a.x1 = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.res = (const bf16*)res; a.y1 = (bf16*)dx;
+  a.Cs = (int)d->Cout; a.K = a.Cs * 8; a.M = (int)d->C1; a.M1 = a.M;
+  a.N = (int)d->N; a.D = (int)d->ID / 2; a.H = (int)d->IH / 2; a.W = (int)d->IW / 2;
+  a.OD = (int)d->OD; a.OH = (int)d->OH; a.OW = (int)d->OW;
+  return pw_launch<PW_S2_DGRAD>(a, 8, s);
+}
+
+// ---- ConvTranspose (kernel == stride) forward and dgrad
+int convT_fwd_mfma(const devis_convT_desc* d, const void* x, const void* w, const float* bias, void* y, hipStream_t s) {
+  if (d->dtype != DEVIS_BF16 || d->Cin % 8 || d->Cout % 4) return DEVIS_ERR_UNSUPPORTED;
+  if (!small_enough(d->N * d->ID * d->IH * d->IW * d->KD * d->KH * d->KW)) return DEVIS_ERR_UNSUPPORTED;
+  PwArgs a = {};
+  a.x1 = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y1 = (bf16*)y;
+  a.C1 = (int)d->Cin; a.C2 = 0; a.K = a.C1; a.Cs = (int)d->Cout;
+  a.KD = d->KD; a.KH = d->KH; a.KW = d->KW;
+  a.M = a.Cs * a.KD * a.KH * a.KW; a.M1 = a.M;
+  a.N = (int)d->N; a.D = (int)d->ID; a.H = (int)d->IH; a.W = (int)d->IW;
+  a.OD = a.D * a.KD; a.OH = a.H * a.KH; a.OW = a.W * a.KW;
+  return pw_launch<PW_CONVT_FWD>(a, 1, s);
+}
+
+// w_t: [Cin][T*Cout] = devis_repack_conv_weight_dgrad(packed convT weight viewed as [T*Cout][1][Cin])
+int convT_dgrad_mfma(const devis_convT_desc* d, const void* dy, const void* w_t, void* dx, hipStream_t s) {
+  if (!w_t || d->dtype != DEVIS_BF16 || d->Cout % 8 || d->Cin % 4) return DEVIS_ERR_UNSUPPORTED;
+  if (!small_enough(d->N * d->ID * d->IH * d->IW * d->KD * d->KH * d->KW)) return DEVIS_ERR_UNSUPPORTED;
+  PwArgs a = {};
+  a.x1 = (const bf16*)dy; a.w = (const bf16*)w_t; a.y1 = (bf16*)dx;
+  a.Cs = (int)d->Cout; a.KD = d->KD; a.KH = d->KH; a.KW = d->KW;
+  a.K = a.Cs * a.KD * a.KH * a.KW; a.M = (int)d->Cin; a.M1 = a.M;
+  a.N = (int)d->N; a.D = (int)d->ID; a.H = (int)d->IH; a.W = (int)d->IW;
+  a.OD = a.D * a.KD; a.OH = a.H * a.KH; a.OW = a.W * a.KW;
+  return pw_launch<PW_CONVT_DGRAD>(a, 1, s);
+}
+
+}  // namespace devis

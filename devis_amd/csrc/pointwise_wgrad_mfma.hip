@@ -1,0 +1,280 @@
+// MFMA weight-gradients of the halo-free layers (bf16 channels-last, gfx950):
+//   1x1 conv (virtual concat):  dW[co][ci]    = sum_v dy[v][co] * x[v][ci]
+//   ConvTranspose k == stride:  dW[ci][co][p] = sum_i x[i][ci]  * dy[2i+p][co]      (one grid.y slice per tap p)
+// K = voxels.  Every wave takes its own 32-voxel K steps: it copies the two [voxel][channel] slabs into a
+// private LDS image ([16-channel tile][32 voxels][32 B], conflict-free for the transposing reads), reads
+// them back with ds_read_b64_tr_b16 and accumulates all (M tile, N tile) pairs in registers.  Per-wave
+// partials go to the workspace; a second kernel adds them in a fixed order (deterministic) and writes the
+// PyTorch fp32 layouts plus dbias.
+#include "common.h"
+#include "mfma_common.h"
+
+namespace devis {
+
+enum { PWG_CONV1 = 0, PWG_CONVT = 1 };
+
+struct PwWgArgs {
+  const bf16* msrc;              // M side: CONV1 dy [V][M];  CONVT x [V][M]
+  const bf16* n1; const bf16* n2;  // N side: CONV1 x1/x2;   CONVT dy [OV][N]
+  int M, N, C1, C2;
+  int NB, D, H, W, KD, KH, KW, OD, OH, OW;
+  int64_t NV;
+  int iters;
+  float* part;                   // [nparts][T][M][N]
+  float* bpart;                  // [nparts][T][Cb] or null
+  int bias_side;                 // 1: bias channels are the M side (CONV1), 2: the N side (CONVT)
+};
+
+__device__ __forceinline__ bf16x8 tr_pair2(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  union { s16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+  return u.v;
+}
+
+// load up to 8 channels [c, c+8) of a row with C channels (C % 4 == 0), zero-extended
+__device__ __forceinline__ uint4 load_piece(const bf16* row, int c, int C) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (c + 8 <= C) v = *reinterpret_cast<const uint4*>(row + c);
+  else if (c + 4 <= C) { const uint2 t = *reinterpret_cast<const uint2*>(row + c); v.x = t.x; v.y = t.y; }
+  return v;
+}
+
+template <int MODE, int MTO, int MTI>
+__global__ void __launch_bounds__(256)
+k_pw_wgrad(PwWgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  char* mimg = smem + wave * (MTO + MTI) * 1024;
+  char* nimg = mimg + MTO * 1024;
+  const int tap = blockIdx.y;
+  const int tw = tap % a.KW, th = (tap / a.KW) % a.KH, td = tap / (a.KW * a.KH);
+
+  f32x4 acc[MTO][MTI];
+#pragma unroll
+  for (int mo = 0; mo < MTO; ++mo)
+#pragma unroll
+    for (int mi = 0; mi < MTI; ++mi) acc[mo][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+  constexpr int MPPV = MTO * 2, NPPV = MTI * 2;       // 16-byte pieces per voxel in the (padded) images
+  for (int it = 0; it < a.iters; ++it) {
+    const int64_t seg = ((int64_t)blockIdx.x * a.iters + it) * 4 + wave;
+    const int64_t v0 = seg * 32;
+    __syncthreads();
+    for (int i = lane; i < 32 * MPPV; i += 64) {
+      const int v = i / MPPV, pc = i % MPPV;
+      const int64_t gv = v0 + v;
+      uint4 val = make_uint4(0u, 0u, 0u, 0u);
+      if (gv < a.NV) val = load_piece(a.msrc + gv * a.M, pc * 8, a.M);
+      if (a.bias_side == 1) {
+        bsum[0] += bf_lo(val.x); bsum[1] += bf_hi(val.x); bsum[2] += bf_lo(val.y); bsum[3] += bf_hi(val.y);
+        bsum[4] += bf_lo(val.z); bsum[5] += bf_hi(val.z); bsum[6] += bf_lo(val.w); bsum[7] += bf_hi(val.w);
+      }
+      *reinterpret_cast<uint4*>(mimg + ((pc >> 1) * 32 + v) * 32 + (pc & 1) * 16) = val;
+    }
+    for (int i = lane; i < 32 * NPPV; i += 64) {
+      const int v = i / NPPV, pc = i % NPPV;
+      const int64_t gv = v0 + v;
+      uint4 val = make_uint4(0u, 0u, 0u, 0u);
+      if (gv < a.NV) {
+        const int c = pc * 8;
+        if (MODE == PWG_CONV1) {
+          if (c < a.C1) val = load_piece(a.n1 + gv * a.C1, c, a.C1);
+          else val = load_piece(a.n2 + gv * a.C2, c - a.C1, a.C2);
+        } else {
+          int64_t r = gv;
+          const int w = (int)(r % a.W); r /= a.W;
+          const int h = (int)(r % a.H); r /= a.H;
+          const int d = (int)(r % a.D);
+          const int n = (int)(r / a.D);
+          const int64_t ov = ((int64_t)(n * a.OD + d * a.KD + td) * a.OH + h * a.KH + th) * a.OW + w * a.KW + tw;
+          val = load_piece(a.n1 + ov * a.N, c, a.N);
+        }
+      }
+      if (a.bias_side == 2) {
+        bsum[0] += bf_lo(val.x); bsum[1] += bf_hi(val.x); bsum[2] += bf_lo(val.y); bsum[3] += bf_hi(val.y);
+        bsum[4] += bf_lo(val.z); bsum[5] += bf_hi(val.z); bsum[6] += bf_lo(val.w); bsum[7] += bf_hi(val.w);
+      }
+      *reinterpret_cast<uint4*>(nimg + ((pc >> 1) * 32 + v) * 32 + (pc & 1) * 16) = val;
+    }
+    __syncthreads();
+    const int vq = 4 * g + q;       // this lane addresses voxel rows vq and 16+vq of the 32-voxel step
+    bf16x8 af[MTO];
+#pragma unroll
+    for (int mo = 0; mo < MTO; ++mo)
+      af[mo] = tr_pair2(mimg + (mo * 32 + vq) * 32 + p * 8, mimg + (mo * 32 + 16 + vq) * 32 + p * 8);
+#pragma unroll
+    for (int mi = 0; mi < MTI; ++mi) {
+      const bf16x8 bfr = tr_pair2(nimg + (mi * 32 + vq) * 32 + p * 8, nimg + (mi * 32 + 16 + vq) * 32 + p * 8);
+#pragma unroll
+      for (int mo = 0; mo < MTO; ++mo)
+        acc[mo][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mo], bfr, acc[mo][mi], 0, 0, 0);
+    }
+  }
+
+  const int T = gridDim.y;
+  const int64_t pidx = (int64_t)blockIdx.x * 4 + wave;
+  float* part = a.part + (pidx * T + tap) * a.M * a.N;
+#pragma unroll
+  for (int mo = 0; mo < MTO; ++mo)
+#pragma unroll
+    for (int mi = 0; mi < MTI; ++mi) {
+      const int n = mi * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = mo * 16 + g * 4 + j;
+        if (m < a.M && n < a.N) part[(int64_t)m * a.N + n] = acc[mo][mi][j];
+      }
+    }
+  if (a.bpart) {
+    // lanes with equal (lane % PPV) hold the same 8 channels: combine them through LDS (fixed order)
+    const int PPV = a.bias_side == 1 ? MPPV : NPPV;
+    const int Cb = a.bias_side == 1 ? a.M : a.N;
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(mimg);      // [64][8] floats = 2 KB <= the wave's own region
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[lane * 8 + j] = bsum[j];
+    __syncthreads();
+    if (lane < PPV * 8) {
+      const int pc = lane / 8, j = lane % 8;
+      float s = 0.f;
+      for (int k = pc; k < 64; k += PPV) s += red[k * 8 + j];
+      if (lane < Cb) a.bpart[(pidx * T + tap) * Cb + lane] = s;
+    }
+  }
+}
+
+// out[(m*N + n)*T + p] = sum_k part[((k*T + p)*M + m)*N + n];  dbias[c] = sum_{k,p} bpart[(k*T + p)*Cb + c]
+// 8 lanes share one output (k = sub, sub+8, ...), combined with a fixed xor tree: deterministic.
+__global__ void __launch_bounds__(256)
+k_pw_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ bpart, int nparts, int T, int M, int N,
+                  int Cb, float* __restrict__ dw, float* __restrict__ dbias) {
+  const int64_t total = (int64_t)M * N * T;
+  const int64_t o = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  float s = 0.f;
+  const bool is_w = o < total;
+  const bool is_b = !is_w && dbias && (o - total) < Cb;
+  if (is_w) {
+    const int p = (int)(o % T);
+    const int64_t mn = o / T;
+    for (int k = sub; k < nparts; k += 8) s += part[((int64_t)k * T + p) * M * N + mn];
+  } else if (is_b) {
+    const int c = (int)(o - total);
+    for (int k = sub; k < nparts * T; k += 8) s += bpart[(int64_t)k * Cb + c];
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (sub == 0) {
+    if (is_w) dw[o] = s;
+    else if (is_b) dbias[o - total] = s;
+  }
+}
+
+struct PwWgPlan { int gx, iters, nparts, T; size_t part_bytes, total_bytes; };
+
+static PwWgPlan pw_plan(int64_t NV, int T, int M, int N, int Cb) {
+  PwWgPlan p;
+  const int64_t segs = cdiv(NV, 32);
+  int64_t gx = cdiv(segs, 4);
+  const int64_t cap = T >= 8 ? 64 : (T >= 4 ? 128 : 256);
+  if (gx > cap) gx = cap;
+  p.gx = (int)gx;
+  p.iters = (int)cdiv(segs, gx * 4);
+  p.nparts = p.gx * 4;
+  p.T = T;
+  p.part_bytes = (size_t)p.nparts * T * M * N * sizeof(float);
+  p.total_bytes = p.part_bytes + (size_t)p.nparts * T * Cb * sizeof(float);
+  return p;
+}
+
+template <int MODE>
+static int pw_wgrad_launch(PwWgArgs& a, const PwWgPlan& pl, int Cb, float* dw, float* dbias, void* ws, hipStream_t s) {
+  a.iters = pl.iters;
+  a.part = (float*)ws;
+  a.bpart = dbias ? (float*)((char*)ws + pl.part_bytes) : nullptr;
+  const int mto = (int)cdiv(a.M, 16), mti = (int)cdiv(a.N, 16);
+  const dim3 grid((unsigned)pl.gx, (unsigned)pl.T);
+#define PWG(MO, MI) hipLaunchKernelGGL((k_pw_wgrad<MODE, MO, MI>), grid, dim3(256), 4 * (MO + MI) * 1024, s, a)
+  if (mto == 4 && mti == 8) PWG(4, 8);
+  else if (mto == 2 && mti == 4) PWG(2, 4);
+  else if (mto == 1 && mti == 2) PWG(1, 2);
+  else if (mto == 1 && mti == 1) PWG(1, 1);
+  else if (mto == 4 && mti == 4) PWG(4, 4);
+  else if (mto == 2 && mti == 2) PWG(2, 2);
+  else return DEVIS_ERR_UNSUPPORTED;
+#undef PWG
+  int rc = launch_status();
+  if (rc) return rc;
+  const int64_t outs = (int64_t)a.M * a.N * pl.T + (dbias ? Cb : 0);
+  hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3((unsigned)cdiv(outs * 8, 256)), dim3(256), 0, s, a.part, a.bpart, pl.nparts,
+                     pl.T, a.M, a.N, Cb, dw, dbias);
+  return launch_status();
+}
+
+static bool pw_tiles_ok(int M, int N) {
+  const int mto = (M + 15) / 16, mti = (N + 15) / 16;
+  return (mto == 4 && mti == 8) || (mto == 2 && mti == 4) || (mto == 1 && mti == 2) || (mto == 1 && mti == 1) ||
+         (mto == 4 && mti == 4) || (mto == 2 && mti == 2);
+}
+
+static bool conv1_wgrad_ok(const devis_conv_desc* d) {
+  if (d->dtype != DEVIS_BF16 || d->KD != 1 || d->KH != 1 || d->KW != 1 || d->SD != 1 || d->SH != 1 || d->SW != 1) return false;
+  if (d->PD || d->PH || d->PW) return false;
+  if (d->Cout % 4 || d->C1 % 8 || d->C2 % 8) return false;
+  return pw_tiles_ok((int)d->Cout, (int)(d->C1 + d->C2));
+}
+
+size_t conv1_wgrad_mfma_workspace(const devis_conv_desc* d) {
+  if (!conv1_wgrad_ok(d)) return 0;
+  return pw_plan(d->N * d->ID * d->IH * d->IW, 1, (int)d->Cout, (int)(d->C1 + d->C2), (int)d->Cout).total_bytes;
+}
+
+int conv1_wgrad_mfma(const devis_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, float* dbias,
+                     void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!conv1_wgrad_ok(d)) return DEVIS_ERR_UNSUPPORTED;
+  PwWgArgs a = {};
+  a.msrc = (const bf16*)dy; a.n1 = (const bf16*)x1; a.n2 = (const bf16*)x2;
+  a.M = (int)d->Cout; a.N = (int)(d->C1 + d->C2); a.C1 = (int)d->C1; a.C2 = (int)d->C2;
+  a.NV = d->N * d->ID * d->IH * d->IW;
+  a.KD = a.KH = a.KW = 1;
+  a.bias_side = dbias ? 1 : 0;
+  const PwWgPlan pl = pw_plan(a.NV, 1, a.M, a.N, a.M);
+  if (!ws || ws_bytes < pl.total_bytes) return DEVIS_ERR_WORKSPACE;
+  return pw_wgrad_launch<PWG_CONV1>(a, pl, a.M, dw, dbias, ws, s);
+}
+
+static bool convT_wgrad_ok(const devis_convT_desc* d) {
+  if (d->dtype != DEVIS_BF16 || d->Cin % 8 || d->Cout % 8) return false;
+  return pw_tiles_ok((int)d->Cin, (int)d->Cout);
+}
+
+size_t convT_wgrad_mfma_workspace(const devis_convT_desc* d) {
+  if (!convT_wgrad_ok(d)) return 0;
+  return pw_plan(d->N * d->ID * d->IH * d->IW, d->KD * d->KH * d->KW, (int)d->Cin, (int)d->Cout, (int)d->Cout).total_bytes;
+}
+
+int convT_wgrad_mfma(const devis_convT_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* ws,
+                     size_t ws_bytes, hipStream_t s) {
+  if (!convT_wgrad_ok(d)) return DEVIS_ERR_UNSUPPORTED;
+  PwWgArgs a = {};
+  a.msrc = (const bf16*)x; a.n1 = (const bf16*)dy;
+  a.M = (int)d->Cin; a.N = (int)d->Cout;
+  a.NB = (int)d->N; a.D = (int)d->ID; a.H = (int)d->IH; a.W = (int)d->IW;
+  a.KD = d->KD; a.KH = d->KH; a.KW = d->KW;
+  a.OD = a.D * a.KD; a.OH = a.H * a.KH; a.OW = a.W * a.KW;
+  a.NV = d->N * d->ID * d->IH * d->IW;
+  a.bias_side = dbias ? 2 : 0;
+  const int T = d->KD * d->KH * d->KW;
+  const PwWgPlan pl = pw_plan(a.NV, T, a.M, a.N, a.N);
+  if (!ws || ws_bytes < pl.total_bytes) return DEVIS_ERR_WORKSPACE;
+  return pw_wgrad_launch<PWG_CONVT>(a, pl, a.N, dw, dbias, ws, s);
+}
+
+}  // namespace devis

@@ -181,7 +181,8 @@ def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, r
     dx2 = torch.empty(tuple(in_shape1[:-1]) + (c2,), dtype=dy.dtype, device=dy.device) if c2 else None
     lib = _lib.load()
     wd = None
-    if dy.dtype == torch.bfloat16 and c2 == 0 and geom.k == (3, 3, 3) and geom.s == (1, 1, 1):
+    if dy.dtype == torch.bfloat16 and ((c2 == 0 and geom.k == (3, 3, 3) and geom.s in ((1, 1, 1), (2, 2, 2)))
+                                       or geom.k == (1, 1, 1)):
         # tap-flipped [Cin][T][Cout] packing: dgrad runs on the MFMA forward kernel
         wd = torch.empty((wp.shape[2], wp.shape[1], wp.shape[0]), dtype=wp.dtype, device=wp.device)
         check(lib.devis_repack_conv_weight_dgrad(_p(wp), _p(wd), wp.shape[0], wp.shape[2], wp.shape[1],
@@ -237,7 +238,14 @@ def convT_dgrad(dy: Tensor, wp: Tensor, k, x_shape) -> Tensor:
     _need_cuda(dy, wp)
     d = _tdesc(x_shape, wp.shape[2], wp.shape[1], k, dy.dtype)
     dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
-    check(_lib.load().devis_convT_dgrad(C.byref(d), _p(dy), _p(wp), _p(dx), _stream()), "convT_dgrad")
+    lib = _lib.load()
+    wt = None
+    if dy.dtype == torch.bfloat16:
+        t, co, ci = wp.shape
+        wt = torch.empty((ci, t * co), dtype=wp.dtype, device=wp.device)
+        check(lib.devis_repack_conv_weight_dgrad(_p(wp), _p(wt), t * co, ci, 1, dt_code(wp.dtype), _stream()),
+              "repack convT weight")
+    check(lib.devis_convT_dgrad(C.byref(d), _p(dy), _p(wp), _p(wt), _p(dx), _stream()), "convT_dgrad")
     return dx
 
 
@@ -247,7 +255,10 @@ def convT_wgrad(x: Tensor, dy: Tensor, k, wshape):
     d = _tdesc(x.shape, cin, cout, k, x.dtype)
     dw = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device)
-    check(_lib.load().devis_convT_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), None, 0, _stream()), "convT_wgrad")
+    lib = _lib.load()
+    nb = lib.devis_convT_wgrad_workspace_bytes(C.byref(d))
+    ws = workspace(nb, x.device) if nb else None
+    check(lib.devis_convT_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, _stream()), "convT_wgrad")
     return dw, db
 
 

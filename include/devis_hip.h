@@ -108,7 +108,10 @@ typedef struct devis_convT_desc {
 } devis_convT_desc;
 int devis_convT_fwd(const devis_convT_desc* d, const void* x, const void* w_packed, const float* bias,
                     void* y, void* stream);
-int devis_convT_dgrad(const devis_convT_desc* d, const void* dy, const void* w_packed, void* dx, void* stream);
+/* w_t: optional [Cin][T*Cout] transpose of the packed weight (devis_repack_conv_weight_dgrad on the packed
+ * weight viewed as [T*Cout][1][Cin]) that lets dgrad run on the MFMA gather-GEMM. */
+int devis_convT_dgrad(const devis_convT_desc* d, const void* dy, const void* w_packed, const void* w_t, void* dx,
+                      void* stream);
 size_t devis_convT_wgrad_workspace_bytes(const devis_convT_desc* d);
 int devis_convT_wgrad(const devis_convT_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                       void* workspace, size_t workspace_bytes, void* stream);
