@@ -25,6 +25,7 @@ struct Conv3Args {
   bf16* y;
   int N, ID, IH, IW, OD, OH, OW, Cout;
   int ntd, nth, ntw;
+  int cin_real;       // 4 for the first layer (zero-extended to 16 in LDS), else CIN
 };
 
 template <int CIN, int COUT_T, int TD, int TH, int TW, int S>
@@ -85,7 +86,7 @@ k_conv3_mfma(Conv3Args a) {
     ubase[j] = ((ltd * S) * C::HH + lth * S) * C::HW + (ltw * 16 + l15) * S;
   }
 
-  const bf16* wrow = a.w + (size_t)(co_base + l15) * 27 * CIN;
+  const bf16* wrow = a.w + (size_t)(co_base + l15) * 27 * a.cin_real;
 
   for (int cc = 0; cc < C::NCH; ++cc) {
     if (cc > 0) __syncthreads();
@@ -107,7 +108,12 @@ k_conv3_mfma(Conv3Args a) {
         const int id = od0 * S - 1 + hd, ih = oh0 * S - 1 + hh, iw = ow0 * S - 1 + hw;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (id >= 0 && id < a.ID && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW) {
-          v = *reinterpret_cast<const uint4*>(a.x + ((size_t)((n * a.ID + id) * a.IH + ih) * a.IW + iw) * CIN + cc * C::CK + piece * 8);
+          const size_t vox = (size_t)((n * a.ID + id) * a.IH + ih) * a.IW + iw;
+          if (CIN == 16 && a.cin_real == 4) {
+            if (piece == 0) { const uint2 t = *reinterpret_cast<const uint2*>(a.x + vox * 4); v.x = t.x; v.y = t.y; }
+          } else {
+            v = *reinterpret_cast<const uint4*>(a.x + vox * CIN + cc * C::CK + piece * 8);
+          }
           if (PRO) {
             unsigned wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -152,11 +158,19 @@ k_conv3_mfma(Conv3Args a) {
         bf16x8 af[C::MT];
 #pragma unroll
         for (int m = 0; m < C::MT; ++m) {
-          const bf16* p = wrow + (size_t)m * 16 * 27 * CIN + (t0 + hi) * 16 + half * 8;
-          bf16x8 z;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
-          af[m] = (2 * c + hi < 27) ? *reinterpret_cast<const bf16x8*>(p) : z;
+          union { uint4 u; bf16x8 v; } f;
+          f.u = make_uint4(0u, 0u, 0u, 0u);
+          if (2 * c + hi < 27) {
+            if (a.cin_real == 4) {
+              if (half == 0) {
+                const uint2 t = *reinterpret_cast<const uint2*>(wrow + (size_t)m * 16 * 27 * 4 + (t0 + hi) * 4);
+                f.u.x = t.x; f.u.y = t.y;
+              }
+            } else {
+              f.u = *reinterpret_cast<const uint4*>(wrow + (size_t)m * 16 * 27 * CIN + (t0 + hi) * 16 + half * 8);
+            }
+          }
+          af[m] = f.v;
         }
         const int toff = hi ? tap_off<C::HH, C::HW>(t1) : tap_off<C::HH, C::HW>(t0);
 #pragma unroll
@@ -207,6 +221,7 @@ static int launch_conv3(const devis_conv_desc* d, const void* x, const void* w, 
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.sc = sc; a.sh = sh; a.res = (const bf16*)res; a.y = (bf16*)y;
   a.N = (int)d->N; a.ID = (int)d->ID; a.IH = (int)d->IH; a.IW = (int)d->IW;
   a.OD = (int)d->OD; a.OH = (int)d->OH; a.OW = (int)d->OW; a.Cout = (int)d->Cout;
+  a.cin_real = (int)d->C1;
   a.ntd = (int)cdiv(d->OD, TD); a.nth = (int)cdiv(d->OH, TH); a.ntw = (int)cdiv(d->OW, TW);
   const int64_t tiles = (int64_t)a.N * a.ntd * a.nth * a.ntw;
   if (tiles > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
@@ -244,6 +259,7 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
   const int ci = (int)d->C1, co = (int)d->Cout, st = d->SD;
   if (st == 1) {
     if (ci == 16 && co == 16) return launch_conv3<16, 16, 8, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
+    if (ci == 4 && co == 16 && !sc) return launch_conv3<16, 16, 8, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
     if (ci == 32 && co == 32) return launch_conv3<32, 32, 4, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
     if (ci == 64 && co == 64) return launch_conv3<64, 64, 4, 4, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
     if (ci == 128 && co == 128) return launch_conv3<128, 64, 2, 4, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);

@@ -19,7 +19,7 @@ struct WgArgs {
   const bf16* dy;    // [N][OD][OH][OW][Cout]
   const float* sc;   // [N][cin_real] or null
   const float* sh;
-  float* part;       // [gx][Cout][Cin][27]
+  float* part;       // [gx][27][Cout][Cin]
   float* bpart;      // [gx][Cout] or null
   int N, ID, IH, IW, OD, OH, OW, Cin, Cout, cin_real;
   int ntd, nth, ntw, ntiles;
@@ -184,7 +184,7 @@ k_wgrad3_mfma(WgArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int co = co0 + mo * 16 + g * 4 + j;
-            part[((size_t)co * a.Cin + ci) * 27 + t] = acc[tt][mo][mi][j];
+            part[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[tt][mo][mi][j];   // ci contiguous over lanes
           }
         }
     }
@@ -204,31 +204,37 @@ k_wgrad3_mfma(WgArgs a) {
   }
 }
 
-// dw[co][ci<cin_real][t] = sum_gx part[gx][co][ci][t];  dbias[co] = sum_gx bpart[gx][co]
+// dw[co][ci<cin_real][t] = sum_gx part[gx][t][co][ci];  dbias[co] = sum_gx bpart[gx][co]
+// 8 lanes share one output (gx = sub, sub+8, ...) and combine with a fixed xor tree: deterministic.
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ bpart, int gx, int Cout, int Cin, int cin_real,
                float* __restrict__ dw, float* __restrict__ dbias) {
-  const int64_t total = (int64_t)Cout * cin_real * 27;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) {
-    const int t = (int)(i % 27);
-    const int ci = (int)((i / 27) % cin_real);
-    const int co = (int)(i / (27 * cin_real));
-    const int64_t src = ((int64_t)co * Cin + ci) * 27 + t;
-    const int64_t stride = (int64_t)Cout * Cin * 27;
-    float s = 0.f;
-    for (int k = 0; k < gx; ++k) s += part[k * stride + src];
-    dw[i] = s;
+  const int64_t total = (int64_t)27 * Cout * Cin;
+  const int64_t o = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const bool is_w = o < total;
+  const bool is_b = !is_w && dbias && (o - total) < Cout;
+  float s = 0.f;
+  if (is_w) {
+    for (int k = sub; k < gx; k += 8) s += part[(int64_t)k * total + o];
+  } else if (is_b) {
+    for (int k = sub; k < gx; k += 8) s += bpart[(int64_t)k * Cout + (o - total)];
   }
-  if (dbias && i < Cout) {
-    float s = 0.f;
-    for (int k = 0; k < gx; ++k) s += bpart[(int64_t)k * Cout + i];
-    dbias[i] = s;
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (sub == 0) {
+    if (is_w) {
+      const int ci = (int)(o % Cin), co = (int)((o / Cin) % Cout), t = (int)(o / ((int64_t)Cin * Cout));
+      if (ci < cin_real) dw[((int64_t)co * cin_real + ci) * 27 + t] = s;
+    } else if (is_b) {
+      dbias[o - total] = s;
+    }
   }
 }
 
 static int wg_gx(int64_t ntiles, int nslab) {
-  int64_t cap = 1024 / nslab;
+  int64_t cap = 512 / nslab;
   if (cap < 8) cap = 8;
   return (int)(ntiles < cap ? ntiles : cap);
 }
@@ -258,8 +264,8 @@ static int launch_wgrad(const devis_conv_desc* d, const void* x, const float* sc
   else hipLaunchKernelGGL((k_wgrad3_mfma<CIS, COS, TD, TH, S, false, SMALLC>), grid, dim3(256), C::LDS_BYTES, s, a);
   int rc = launch_status();
   if (rc) return rc;
-  const int64_t n_out = (int64_t)Cout * cin_real * 27;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv(n_out > Cout ? n_out : Cout, 256)), dim3(256), 0, s,
+  const int64_t n_out = (int64_t)Cout * Cin * 27 + (dbias ? Cout : 0);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv(n_out * 8, 256)), dim3(256), 0, s,
                      a.part, a.bpart, gx, Cout, Cin, cin_real, dw, dbias);
   return launch_status();
 }

@@ -132,10 +132,20 @@ k_evid_fwd(const T* __restrict__ z, EvidShape s, const void* __restrict__ labels
 }
 
 __global__ void k_evid_finalize(const double* __restrict__ partial, int blocks, int K, double NV, float* __restrict__ scal) {
+  // 256 threads: accumulator i = tid % 32, block slice = tid / 32; slices combined in a fixed order
   __shared__ double tot[EV_NACC];
+  __shared__ double red[8][32];
+  {
+    const int i = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double a = 0.0;
+    if (i < EV_NACC)
+      for (int b = sl; b < blocks; b += 8) a += partial[(int64_t)b * EV_NACC + i];
+    red[sl][i] = a;
+  }
+  __syncthreads();
   if (threadIdx.x < EV_NACC) {
     double a = 0.0;
-    for (int b = 0; b < blocks; ++b) a += partial[(int64_t)b * EV_NACC + threadIdx.x];
+    for (int sl = 0; sl < 8; ++sl) a += red[sl][threadIdx.x];
     tot[threadIdx.x] = a;
   }
   __syncthreads();
@@ -291,7 +301,7 @@ int devis_evid_loss_fwd(const void* logits, int64_t sN, int64_t sV, int64_t sK, 
   DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_evid_fwd<T>, dim3(blocks), dim3(256), 0, s, (const T*)logits, sh, labels, label_dtype, lambda, evidence_out, per_voxel_out, (double*)ws));
   int rc = launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(k_evid_finalize, dim3(1), dim3(64), 0, s, (const double*)ws, (int)blocks, (int)K, (double)(N * V), scal);
+  hipLaunchKernelGGL(k_evid_finalize, dim3(1), dim3(256), 0, s, (const double*)ws, (int)blocks, (int)K, (double)(N * V), scal);
   return launch_status();
 }
 

@@ -106,13 +106,19 @@ k_moments(const T* __restrict__ x, const T* __restrict__ dy, const float* __rest
 
 // out[n][c][j] = sum_chunk partial[n][chunk][c][j]
 __global__ void k_moments_final(const double* __restrict__ partial, int64_t chunks, int64_t C, int64_t total, double* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over N*C*2
-  if (i >= total) return;
-  const int64_t n = i / (C * 2), rem = i % (C * 2);
-  const double* p = partial + n * chunks * C * 2 + rem;
+  // 8 lanes per output (chunk = sub, sub+8, ...), combined with a fixed xor tree: deterministic
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;   // over N*C*2
+  const int sub = threadIdx.x & 7;
   double a = 0.0;
-  for (int64_t k = 0; k < chunks; ++k) a += p[k * C * 2];
-  out[i] = a;
+  if (i < total) {
+    const int64_t n = i / (C * 2), rem = i % (C * 2);
+    const double* p = partial + n * chunks * C * 2 + rem;
+    for (int64_t k = sub; k < chunks; k += 8) a += p[k * C * 2];
+  }
+  a += __shfl_xor(a, 1, 64);
+  a += __shfl_xor(a, 2, 64);
+  a += __shfl_xor(a, 4, 64);
+  if (i < total && sub == 0) out[i] = a;
 }
 
 __global__ void k_gn_finalize(const double* __restrict__ mom, int64_t N, int64_t V, int64_t C, int64_t G,
@@ -354,7 +360,7 @@ static int moments_impl(int mode, const void* x, const void* dy, const float* sc
   int rc = launch_status();
   if (rc) return rc;
   const int64_t total = N * C * 2;
-  hipLaunchKernelGGL(k_moments_final, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const double*)ws, chunks, C, total, out);
+  hipLaunchKernelGGL(k_moments_final, dim3((unsigned)cdiv(total * 8, 256)), dim3(256), 0, s, (const double*)ws, chunks, C, total, out);
   return launch_status();
 }
 

@@ -24,14 +24,22 @@ struct PwArgs {
   int64_t ntiles;
 };
 
+// 8 channels [c, c+8) of a row holding C channels (C % 4 == 0), zero-extended past the end
+__device__ __forceinline__ uint4 pw_piece(const bf16* row, int c, int C) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (c + 8 <= C) v = *reinterpret_cast<const uint4*>(row + c);
+  else if (c + 4 <= C) { const uint2 t = *reinterpret_cast<const uint2*>(row + c); v.x = t.x; v.y = t.y; }
+  return v;
+}
+
 template <int MODE>
 __device__ __forceinline__ uint4 pw_load_b(const PwArgs& a, int k0, int n, int d, int h, int w, bool vox_ok, int cls) {
   uint4 z = make_uint4(0u, 0u, 0u, 0u);
   if (!vox_ok || k0 >= a.K) return z;
   if (MODE == PW_CONV1 || MODE == PW_CONVT_FWD) {
     const size_t v = ((size_t)(n * a.D + d) * a.H + h) * a.W + w;
-    if (k0 < a.C1) return *reinterpret_cast<const uint4*>(a.x1 + v * a.C1 + k0);
-    return *reinterpret_cast<const uint4*>(a.x2 + v * a.C2 + (k0 - a.C1));
+    if (k0 < a.C1) return pw_piece(a.x1 + v * a.C1, k0, a.C1);
+    return pw_piece(a.x2 + v * a.C2, k0 - a.C1, a.C2);
   } else if (MODE == PW_CONVT_DGRAD) {
     const int p = k0 / a.Cs, c = k0 % a.Cs;
     const int pw = p % a.KW, ph = (p / a.KW) % a.KH, pd = p / (a.KW * a.KH);
@@ -56,7 +64,7 @@ template <int MODE>
 __device__ __forceinline__ uint4 pw_load_a(const PwArgs& a, int m, int k0, int cls) {
   uint4 z = make_uint4(0u, 0u, 0u, 0u);
   if (m >= a.M || k0 >= a.K) return z;
-  if (MODE != PW_S2_DGRAD) return *reinterpret_cast<const uint4*>(a.w + (size_t)m * a.K + k0);
+  if (MODE != PW_S2_DGRAD) return pw_piece(a.w + (size_t)m * a.K, k0, a.K);
   const int tj = k0 / a.Cs, c = k0 % a.Cs;
   const int bw = cls & 1, bh = (cls >> 1) & 1, bd = (cls >> 2) & 1;
   int bit = 0;
@@ -188,7 +196,7 @@ int conv1_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, con
                    const void* res, void* y, hipStream_t s) {
   if (d->dtype != DEVIS_BF16 || d->KD != 1 || d->KH != 1 || d->KW != 1 || d->SD != 1 || d->SH != 1 || d->SW != 1) return DEVIS_ERR_UNSUPPORTED;
   if (d->PD || d->PH || d->PW) return DEVIS_ERR_UNSUPPORTED;
-  if (d->C1 % 8 || d->C2 % 8 || d->Cout % 4) return DEVIS_ERR_UNSUPPORTED;
+  if (d->C1 % 4 || d->C2 % 8 || d->Cout % 4 || (d->C2 && d->C1 % 8)) return DEVIS_ERR_UNSUPPORTED;
   if (!small_enough(d->N * d->ID * d->IH * d->IW)) return DEVIS_ERR_UNSUPPORTED;
   PwArgs a = {};
   a.x1 = (const bf16*)x1; a.x2 = (const bf16*)x2; a.w = (const bf16*)w; a.bias = bias; a.res = (const bf16*)res;
@@ -203,7 +211,7 @@ int conv1_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_t, 
                      hipStream_t s) {
   if (!w_t || d->dtype != DEVIS_BF16 || d->KD != 1 || d->KH != 1 || d->KW != 1 || d->SD != 1 || d->SH != 1 || d->SW != 1) return DEVIS_ERR_UNSUPPORTED;
   if (d->PD || d->PH || d->PW) return DEVIS_ERR_UNSUPPORTED;
-  if (d->Cout % 8 || d->C1 % 16 || d->C2 % 4) return DEVIS_ERR_UNSUPPORTED;    // M tiles must not straddle dx1/dx2
+  if (d->Cout % 4 || d->C1 % 16 || d->C2 % 4) return DEVIS_ERR_UNSUPPORTED;    // M tiles must not straddle dx1/dx2
   if (!small_enough(d->N * d->ID * d->IH * d->IW)) return DEVIS_ERR_UNSUPPORTED;
   PwArgs a = {};
   a.x1 = (const bf16*)dy; a.w = (const bf16*)w_t; a.res = (const bf16*)res;
