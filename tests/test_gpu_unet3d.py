@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import brats_args, rel_err, sd_hash
+from tests.util import GRAD_L2_TOL, GRAD_MAX_TOL, brats_args, l2_rel_err, rel_err, sd_hash
 
 pytestmark = pytest.mark.gpu
 
@@ -50,11 +50,11 @@ def test_train_step_fp32_vs_golden(golden, seed, epoch):
     for k in WATCH:
         g = params[k].grad
         g = g.reshape(-1)[::37] if g.numel() > 20000 else g
-        assert rel_err(g, G[pre + "grad_" + k]) < 2e-4, k
+        assert l2_rel_err(g, G[pre + "grad_" + k]) < GRAD_L2_TOL and rel_err(g, G[pre + "grad_" + k]) < GRAD_MAX_TOL, k
     norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
     # biases that feed a norm layer have mathematically-zero gradients (pure rounding noise): atol covers them
     ref = G[pre + "gradnorm_all"]
-    assert np.all(np.abs(norms - ref) <= 2e-4 * ref + 1e-6 * ref.max()), np.max(np.abs(norms - ref) / (ref + 1e-30))
+    assert np.all(np.abs(norms - ref) <= GRAD_L2_TOL * ref + 1e-6 * ref.max()), np.max(np.abs(norms - ref) / (ref + 1e-30))
     sd = m.backbone.state_dict()
     for k in ("DeBlock2.bn2.running_mean", "DeBlock2.bn2.running_var", "DeBlock4.bn1.running_mean",
               "DeBlock4.bn1.running_var"):
@@ -114,7 +114,7 @@ def test_input_gradient_fp32():
     (net(xg) * w.cuda()).sum().backward()
     xr = x.clone().requires_grad_(True)
     (O.unet3d_forward(sd, xr, True) * w).sum().backward()
-    assert rel_err(xg.grad, xr.grad) < 2e-4
+    assert l2_rel_err(xg.grad, xr.grad) < GRAD_L2_TOL
 
 
 def test_shape_errors():

@@ -27,3 +27,21 @@ def brats_args(**kw):
              lambda_epochs=50, Uncertainty_Loss=False)
     d.update(kw)
     return argparse.Namespace(**d)
+
+
+def l2_rel_err(a, b):
+    """||a-b||_2 / ||b||_2 (b = reference)."""
+    a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).double().cpu()
+    b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+# End-to-end GRADIENT tolerances (fp32 path).  Every kernel is checked against torch fp64 to ~1e-6 in
+# tests/test_gpu_ops.py; end to end, however, a ReLU gate whose pre-activation is within rounding of zero
+# can open on one side and stay shut on the other (GPU fp32 vs CPU fp32 sum order).  One such flip moves
+# that voxel's gradient by O(1) and a weight gradient by ~1/voxels: observed up to 3e-3 on the small
+# golden volumes (measured: the oracle's own h.grad equals BN-backward of its inputs to 1e-7, ours equals
+# fp64 BN-backward of ours to 1e-6, inputs agree to 1e-6, and the two outputs differ only at flipped gates).
+GRAD_L2_TOL = 5e-3
+GRAD_MAX_TOL = 2e-2
