@@ -1,0 +1,51 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel pieces: gradient averaging and patch sharding."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from devis_amd.parallel import GradientAllReducer, broadcast_parameters
+    torch.manual_seed(100 + rank)                       # different replicas on purpose
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    broadcast_parameters(net)                            # -> rank 0's weights everywhere
+    w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    for p in net.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    net[1].bias.grad = None                               # a parameter without gradient must still line up
+    GradientAllReducer(net.parameters(), bucket_bytes=64).all_reduce()
+    g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    q.put((rank, w0, g))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_and_broadcast_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w_a, g_a), (_, w_b, g_b) = res
+    assert torch.equal(w_a, w_b)                          # broadcast made the replicas identical
+    assert torch.equal(g_a, g_b)
+    n_bias = 3
+    assert torch.allclose(g_a[:-n_bias], torch.full_like(g_a[:-n_bias], 1.5))   # mean of 1 and 2
+    assert torch.allclose(g_a[-n_bias:], torch.zeros(n_bias))                   # missing grads count as zero
+
+
+def test_patch_sharding_covers_all_patches():
+    from devis_amd.parallel import shard_patches
+    for world in (1, 2, 3, 4, 8):
+        got = sorted(i for r in range(world) for i in shard_patches(8, r, world))
+        assert got == list(range(8))

@@ -1,0 +1,185 @@
+"""CPU suite (no GPU): the oracle against the golden vectors produced from the real reference, the
+host-side logic, and the C-ABI library's symbol table."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import brats_args, rel_err, sd_hash
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ oracle vs golden
+@pytest.mark.parametrize("tag,K", [("head3d", 4), ("head2d", 2)])
+@pytest.mark.parametrize("variant", ["dce", "dceu"])
+@pytest.mark.parametrize("epoch", [1, 25, 50, 80])
+def test_oracle_head_matches_reference_vectors(golden, tag, K, variant, epoch):
+    from oracle import devis_oracle as O
+    G = golden("head")
+    z = torch.from_numpy(G[tag + "_logits"]).requires_grad_(True)
+    lab = torch.from_numpy(G[tag + "_labels"])
+    ev = F.softplus(z)
+    fn = O.dce_evidence_loss if variant == "dce" else O.dce_evidence_u_loss
+    pv = fn(lab, ev + 1, K, epoch, 50, 100, 1e-10, False, ev, torch.softmax(z, 1))
+    loss = pv.mean()
+    loss.backward()
+    pre = "%s_%s_e%d_" % (tag, variant, epoch)
+    assert rel_err(pv.detach(), G[pre + "per_voxel"]) < 1e-6
+    assert abs(loss.item() - float(G[pre + "loss"])) < 1e-6
+    assert rel_err(z.grad, G[pre + "grad"]) < 1e-5
+    assert rel_err(ev.detach(), G[tag + "_evidence"]) < 1e-6
+
+
+def test_oracle_kl_ce_mse(golden):
+    from oracle import devis_oracle as O
+    G = golden("head")
+    ev = torch.from_numpy(G["head3d_evidence"])
+    assert rel_err(O.kl_dirichlet(O._rows(ev + 1), 4), G["head3d_KL"]) < 1e-6
+    al, lab = torch.from_numpy(G["ce_alpha"]), torch.from_numpy(G["ce_labels"])
+    assert rel_err(O.ce_loss(lab, al, 4, 10, 50), G["ce_loss"]) < 1e-6
+    assert rel_err(O.mse_loss(lab.view(-1), O._rows(al), 4, 10, 50), G["mse_loss"]) < 1e-6
+
+
+def test_oracle_infer_head(golden):
+    from oracle import devis_oracle as O
+    G = golden("head")
+    for tag, K in (("head3d", 4), ("head2d", 2)):
+        pred, u, prob, mne = O.infer_head(torch.from_numpy(G[tag + "_evidence"]), K)
+        assert np.array_equal(pred.numpy().astype(np.uint8), G[tag + "_pred"])
+        assert rel_err(u, G[tag + "_u"]) < 1e-6 and rel_err(mne, G[tag + "_mne"]) < 1e-5
+
+
+def test_oracle_unet3d_train_step(golden):
+    """Seeded init of the PRODUCT module == the reference's; the oracle reproduces loss, grads, BN buffers."""
+    from oracle import devis_oracle as O
+    from devis_amd import Unet
+    G = golden("unet3d")
+    pre = "s1_e25_"
+    shape = tuple(int(v) for v in G[pre + "shape"])
+    torch.manual_seed(1)
+    net = Unet(4, 16, 4)
+    assert sd_hash(net.state_dict()) == str(G[pre + "sd_hash"])
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    for k in sd:
+        if sd[k].is_floating_point():
+            sd[k].requires_grad_(k.split('.')[-1] in ("weight", "bias"))
+    g = torch.Generator().manual_seed(1001)
+    x = torch.randn(shape, generator=g)
+    y = torch.randint(0, 4, (shape[0],) + shape[2:], generator=g)
+    ev, loss = O.tmsu_forward(lambda t: O.unet3d_forward(sd, t, True), x, y, 25, 'train', 'BraTS', 4, 50, 100)
+    loss.backward()
+    assert abs(loss.item() - float(G[pre + "loss"])) < 1e-6
+    assert rel_err(ev.detach()[..., ::2], G[pre + "evidence"]) < 1e-5
+    assert rel_err(sd["endconv.weight"].grad, G[pre + "grad_endconv.weight"]) < 1e-4
+    assert rel_err(sd["DeBlock2.bn2.running_var"], G[pre + "buf_DeBlock2.bn2.running_var"]) < 1e-6
+
+
+def test_oracle_unet2d_rand_padding(golden):
+    from oracle import devis_oracle as O
+    from devis_amd import Unet2D
+    G = golden("unet2d")
+    tag = "u2d_w76"
+    shape = tuple(int(v) for v in G[tag + "_shape"])
+    torch.manual_seed(3)
+    net = Unet2D(3, 2)
+    assert sd_hash(net.state_dict()) == str(G[tag + "_sd_hash"])
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(2000)
+    x = torch.randn(shape, generator=g)
+    torch.manual_seed(99)
+    log = []
+    with torch.no_grad():
+        logits = O.unet2d_forward(sd, x, True, False, log)
+    assert rel_err(logits, G[tag + "_logits"]) < 1e-5
+    assert [list(s) + [0] * (4 - len(s)) for s in log] == G[tag + "_rand_shapes"].tolist()
+
+
+def test_oracle_tailor_and_concat(golden):
+    from oracle import devis_oracle as O
+    G = golden("tailor")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, 4, 240, 240, 160), generator=g)
+    a = O.tailor_and_concat(x, lambda t: t * 2 + 1)
+    assert hashlib.sha256(a.contiguous().numpy().tobytes()).hexdigest() == str(G["fake_sha256"])
+    idx = torch.from_numpy(G["fake_idx"])
+    assert np.array_equal(a.reshape(-1)[idx].numpy(), G["fake_val"])
+
+
+# ------------------------------------------------------------------ host logic
+def test_tailor_regions_tile_the_volume():
+    from devis_amd.predict import CROPS, patch_regions
+    cover = np.zeros((240, 240, 155), dtype=np.int32)
+    for i in range(len(CROPS)):
+        dst, src = patch_regions(i)
+        cover[dst] += 1
+        for d, s in zip(dst, src):
+            assert d.stop - d.start == s.stop - s.start
+    assert (cover == 1).all()
+
+
+def test_product_tailor_matches_oracle_on_cpu_callable():
+    from oracle import devis_oracle as O
+    from devis_amd.predict import tailor_and_concat
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((1, 4, 240, 240, 160), generator=g)
+    fn = lambda t: t * 3 - 1            # noqa: E731  (plain torch callable: the stitch itself is only copies)
+    assert torch.equal(tailor_and_concat(x, fn), O.tailor_and_concat(x, fn))
+    x1 = x[:, :1].contiguous()
+    fn4 = lambda t: torch.cat([t, t * 2, t * 3, t * 4], 1)   # noqa: E731
+    assert torch.equal(tailor_and_concat(x1, fn4), O.tailor_and_concat(x1, fn4))
+
+
+def test_poly_lr_and_args():
+    from oracle import devis_oracle as O
+    from devis_amd.train import adjust_learning_rate, getArgs
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=0.002)
+    for ep in (0, 1, 25, 98):
+        adjust_learning_rate(opt, ep, 99, 0.002)
+        assert opt.param_groups[0]['lr'] == O.poly_lr(0.002, ep, 99)
+    a = getArgs(["--dataset", "BraTS"])
+    assert (a.lr, a.lambda_epochs, a.end_epochs, a.batch_size, a.num_classes) == (0.002, 50, 99, 2, 4)
+    assert a.model_name == 'U' and a.input_modality == 'four' and a.Uncertainty_Loss is False
+
+
+def test_tmsu_selection_and_errors():
+    from devis_amd import TMSU, Unet, Unet2D, Unet2DDRIVE
+    m = TMSU(brats_args())
+    assert isinstance(m.backbone, Unet) and m.classes == 4 and m.total_epochs == 100 and m.eps == 1e-10
+    assert m.disentangle is False and m.lambda_epochs == 50
+    assert isinstance(TMSU(brats_args(dataset='DRIVE', num_classes=2)).backbone, Unet2DDRIVE)
+    assert isinstance(TMSU(brats_args(dataset='HC', num_classes=2)).backbone, Unet2D)
+    with pytest.raises(NameError):
+        TMSU(brats_args(dataset='nope'))
+    with pytest.raises(NameError):
+        TMSU(brats_args(model_name='XYZ'))
+    keys = list(m.state_dict().keys())
+    assert keys[0] == 'backbone.InitConv.conv.weight' and 'backbone.DeBlock2.bn2.num_batches_tracked' in keys
+
+
+def test_no_cpu_fallback():
+    from devis_amd import Unet, _lib, ops
+    with pytest.raises(_lib.DevisError):
+        ops.to_channels_last(torch.zeros(1, 4, 8, 8, 8), torch.float32)
+    with pytest.raises(_lib.DevisError):
+        Unet(4, 16, 4)(torch.zeros(1, 4, 8, 8, 8))
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from devis_amd import _lib
+    header = open(os.path.join(ROOT, "include", "devis_hip.h")).read()
+    declared = set(re.findall(r"\b(devis_[a-zA-Z0-9_]+)\s*\(", header))
+    declared -= {"devis_status", "devis_dtype", "devis_label_dtype"}
+    assert len(declared) > 25
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libdevis_hip.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "%s has no ctypes signature" % name
+    assert lib.devis_version() >= 100
+    assert lib.devis_evid_workspace_bytes(1, 8, 4) > 0       # pure host arithmetic, no GPU touched
