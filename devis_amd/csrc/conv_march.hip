@@ -1,0 +1,282 @@
+// Plane-marching MFMA 3x3x3 convolution for the 16-channel, full-resolution layers (bf16,
+// channels-last, stride 1, gfx950).  These layers carry 216 FLOP per byte of activation traffic,
+// below the MI355X ridge, so the kernel is organised around HBM, not around the matrix cores:
+//
+//   * a block owns an (TH x TW) column of the volume and walks it along D.  A ring of R = 4 input
+//     planes (halo included) lives in LDS; while the MFMAs of output plane d run, plane d+2 is in
+//     flight from HBM in registers, and is written to the ring slot plane d-2 has just vacated.
+//     Every input voxel is fetched once per block (halo only in H and W: 1.33x for 8x32).
+//   * all 27*16*16 weights are A fragments held in 56 VGPRs for the whole walk.
+//   * GEMM orientation as conv_mfma.hip: M = cout, N = 16 voxels along W, K = (2 taps x 16 ci); a
+//     lane's B fragment is one ds_read_b128 (32-byte voxel pitch: conflict-free), its result is 4
+//     consecutive cout of one voxel -> 8-byte channels-last stores.
+//   * the preceding GroupNorm/BatchNorm affine + ReLU is applied on the way into LDS, bias and
+//     the residual add on the way out.
+//   * the walk loop has no divergent or data-dependent branch around a memory instruction (loads
+//     go to clamped addresses and are zeroed by select), so the compiler can count its waits:
+//     the prefetch stays in flight across the MFMAs and the output stores across the barrier.
+#include "common.h"
+#include "mfma_common.h"
+
+#include <stdlib.h>
+
+namespace devis {
+
+struct MarchArgs {
+  const bf16* x;
+  const bf16* w;      // [16][27][cin_real]
+  const float* bias;  // [16] or null
+  const float* sc;    // [N][16] or null
+  const float* sh;
+  const bf16* res;    // like y, or null
+  bf16* y;
+  int N, D, H, W;
+  int nth, ntw, ndc, DL;
+};
+
+// FULL: H % TH == 0 and W % TW == 0 (no partial tiles -> unconditional stores)
+template <int TH, int TW, bool PRO, bool RES, bool CIN4, bool FULL>
+__global__ void __launch_bounds__(256)
+k_conv3_c16_march(MarchArgs a) {
+  constexpr int HH = TH + 2, HW = TW + 2, HP = HH * HW;
+  constexpr int NPT = (HP * 2 + 255) / 256;    // 16-byte pieces per thread per plane
+  constexpr int PLB = NPT * 256 * 16;          // bytes per LDS plane (tail padding: no store guard)
+  constexpr int R = 4;
+  constexpr int NTW = TW / 16;
+  constexpr int NT = TH * NTW / 4;             // N tiles per wave per plane
+  constexpr int CINR = CIN4 ? 4 : 16;
+  static_assert((TH * NTW) % 4 == 0 && NT % NTW == 0, "a wave's N tiles must cover whole rows");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4, half = lq & 1, hi = lq >> 1;
+
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int twi = tile % a.ntw;
+  const int thi = (tile / a.ntw) % a.nth;
+  const int dci = (tile / (a.ntw * a.nth)) % a.ndc;
+  const int n = tile / (a.ntw * a.nth * a.ndc);
+  const int oh0 = thi * TH, ow0 = twi * TW;
+  const int d0 = dci * a.DL;
+  const int d1 = min(d0 + a.DL, a.D);
+  const size_t plane = (size_t)a.H * a.W;
+
+  // ---- A fragments: chunk c = taps (2c, 2c+1) x 16 ci; lanes 0-31 tap 2c, lanes 32-63 tap 2c+1
+  bf16x8 af[14];
+  {
+    const bf16* wrow = a.w + (size_t)l15 * 27 * CINR;
+#pragma unroll
+    for (int c = 0; c < 14; ++c) {
+      union { uint4 u; bf16x8 v; } f;
+      f.u = make_uint4(0u, 0u, 0u, 0u);
+      if (2 * c + hi < 27) {
+        if (CIN4) {
+          if (half == 0) {
+            const uint2 t = *reinterpret_cast<const uint2*>(wrow + (2 * c + hi) * 4);
+            f.u.x = t.x; f.u.y = t.y;
+          }
+        } else {
+          f.u = *reinterpret_cast<const uint4*>(wrow + (2 * c + hi) * 16 + half * 8);
+        }
+      }
+      af[c] = f.v;
+    }
+  }
+
+  // ---- per-thread load slots of one halo plane (the same for every plane)
+  unsigned goff[NPT];
+  bool ok[NPT];
+  const int piece = tid & 1;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int i = tid + k * 256;
+    const int u = i >> 1;
+    const int hh = u / HW, hw = u - hh * HW;
+    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+    ok[k] = i < HP * 2 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && !(CIN4 && piece);
+    goff[k] = ok[k] ? (unsigned)((ih * a.W + iw) * CINR + (CIN4 ? 0 : piece * 8)) : 0u;
+  }
+  float scv[8], shv[8];
+  if (PRO) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      scv[j] = a.sc[n * 16 + piece * 8 + j];
+      shv[j] = a.sh[n * 16 + piece * 8 + j];
+    }
+  }
+
+  // plane id is clamped for the address (always a real plane) and zeroed by store_plane when outside
+  auto load_plane = [&](int id, uint4 (&rg)[NPT]) {
+    const int idc = min(max(id, 0), a.D - 1);
+    const bf16* xp = a.x + ((size_t)n * a.D + idc) * plane * CINR;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      if (CIN4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(xp + goff[k]);
+        rg[k] = make_uint4(t.x, t.y, 0u, 0u);
+      } else {
+        rg[k] = *reinterpret_cast<const uint4*>(xp + goff[k]);
+      }
+    }
+  };
+  auto store_plane = [&](int id, int slot, uint4 (&rg)[NPT]) {
+    const bool pin = id >= 0 && id < a.D;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      uint4 v = rg[k];
+      if (PRO) v = affine_relu8(v, scv, shv);
+      const bool keep = pin && ok[k];
+      v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+      *reinterpret_cast<uint4*>(smem + slot * PLB + (tid + k * 256) * 16) = v;
+    }
+  };
+
+  // ---- fill the ring with planes d0-1, d0, d0+1
+  {
+    uint4 r0[NPT], r1[NPT], r2[NPT];
+    load_plane(d0 - 1, r0);
+    load_plane(d0, r1);
+    load_plane(d0 + 1, r2);
+    store_plane(d0 - 1, 0, r0);
+    store_plane(d0, 1, r1);
+    store_plane(d0 + 1, 2, r2);
+  }
+  __syncthreads();
+
+  // lane part of the B-fragment address; N tile j of the wave adds a compile-time offset
+  const int lanebase = (wave * (NT / NTW) * HW + l15) * 32 + half * 16;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + lq * 4);
+
+  // per-lane output slots inside a plane (element offsets), clamped when the tile is partial
+  unsigned ooff[NT];
+  bool oin[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int oh = oh0 + wave * (NT / NTW) + j / NTW, ow = ow0 + (j % NTW) * 16 + l15;
+    oin[j] = FULL || (oh < a.H && ow < a.W);
+    ooff[j] = oin[j] ? (unsigned)((oh * a.W + ow) * 16 + lq * 4) : 0u;
+  }
+
+  const int np = d1 - d0;
+  for (int it = 0; it < np; ++it) {
+    const int od = d0 + it;
+    uint4 pre[NPT];
+    load_plane(od + 2, pre);                    // consumed by iteration it+1 (harmless on the last one)
+    const size_t pbase = ((size_t)n * a.D + od) * plane * 16;
+    uint2 rv[NT];
+    if (RES) {
+      const bf16* rp = a.res + pbase;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) rv[j] = *reinterpret_cast<const uint2*>(rp + ooff[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    int sb[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) sb[kd] = ((it + kd) & (R - 1)) * PLB;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // B fragments are double-buffered: the reads of chunk c+1 are in flight under the MFMAs of
+    // chunk c (the scheduling barriers keep the compiler from folding them back into one register)
+    auto read_b = [&](int c, bf16x8 (&b)[NT]) {
+      const int t0 = 2 * c, t1 = 2 * c + 1 < 27 ? 2 * c + 1 : 26;   // phantom tap 27: real data x zero weights
+      const int b0 = sb[t0 / 9] + (((t0 / 3) % 3) * HW + t0 % 3) * 32;
+      const int b1 = sb[t1 / 9] + (((t1 / 3) % 3) * HW + t1 % 3) * 32;
+      const char* p = smem + (hi ? b1 : b0) + lanebase;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(p + ((j / NTW) * HW + (j % NTW) * 16) * 32);
+    };
+    bf16x8 bA[NT], bB[NT];
+    read_b(0, bA);
+#pragma unroll
+    for (int c = 0; c < 14; c += 2) {
+      read_b(c + 1, bB);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bA[j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < 14) read_b(c + 2, bA);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c + 1], bB[j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue of plane od
+    bf16* yp = a.y + pbase;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float v0 = acc[j][0] + bv.x, v1 = acc[j][1] + bv.y, v2 = acc[j][2] + bv.z, v3 = acc[j][3] + bv.w;
+      if (RES) { v0 += bf_lo(rv[j].x); v1 += bf_hi(rv[j].x); v2 += bf_lo(rv[j].y); v3 += bf_hi(rv[j].y); }
+      uint2 o;
+      o.x = pack_bf2(v0, v1);
+      o.y = pack_bf2(v2, v3);
+      if (FULL || oin[j]) *reinterpret_cast<uint2*>(yp + ooff[j]) = o;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    store_plane(od + 2, (it + 3) & (R - 1), pre);
+    __syncthreads();
+  }
+}
+
+template <int TH, int TW, bool PRO, bool RES, bool CIN4>
+static void launch_march_v(bool full, dim3 grid, hipStream_t s, const MarchArgs& a) {
+  constexpr int LDS = 4 * (((TH + 2) * (TW + 2) * 2 + 255) / 256) * 256 * 16;
+  if (full) hipLaunchKernelGGL((k_conv3_c16_march<TH, TW, PRO, RES, CIN4, true>), grid, dim3(256), LDS, s, a);
+  else hipLaunchKernelGGL((k_conv3_c16_march<TH, TW, PRO, RES, CIN4, false>), grid, dim3(256), LDS, s, a);
+}
+
+template <int TH, int TW>
+static int launch_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
+                        const float* sh, const void* res, void* y, hipStream_t s) {
+  MarchArgs a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.sc = sc; a.sh = sh; a.res = (const bf16*)res; a.y = (bf16*)y;
+  a.N = (int)d->N; a.D = (int)d->OD; a.H = (int)d->OH; a.W = (int)d->OW;
+  a.nth = (int)cdiv(a.H, TH); a.ntw = (int)cdiv(a.W, TW);
+  // D chunk: enough blocks to fill 256 CUs about twice; each chunk re-reads 2 halo planes
+  static int dl_env = -1;
+  if (dl_env < 0) { const char* e = getenv("DEVIS_MARCH_DL"); dl_env = e ? atoi(e) : 0; }
+  int dl = dl_env > 0 ? dl_env : 32;
+  if (dl_env <= 0) {
+    const int64_t cols = (int64_t)a.N * a.nth * a.ntw;
+    while (dl > 8 && cols * cdiv(a.D, dl) < 512) dl >>= 1;
+  }
+  a.DL = dl;
+  a.ndc = (int)cdiv(a.D, dl);
+  const int64_t tiles = (int64_t)a.N * a.ndc * a.nth * a.ntw;
+  if (tiles > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)tiles);
+  const bool full = a.H % TH == 0 && a.W % TW == 0;
+  if (d->C1 == 4) {
+    if (sc || res) return DEVIS_ERR_UNSUPPORTED;
+    launch_march_v<TH, TW, false, false, true>(full, grid, s, a);
+  } else if (sc) {
+    if (res) launch_march_v<TH, TW, true, true, false>(full, grid, s, a);
+    else launch_march_v<TH, TW, true, false, false>(full, grid, s, a);
+  } else {
+    if (res) launch_march_v<TH, TW, false, true, false>(full, grid, s, a);
+    else launch_march_v<TH, TW, false, false, false>(full, grid, s, a);
+  }
+  return launch_status();
+}
+
+// stride-1 3x3x3, Cout = 16, Cin = 16 (or 4: the first layer), bf16; anything else is unsupported
+int conv3_c16_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
+                    const float* sh, const void* res, void* y, hipStream_t s) {
+  if (d->dtype != DEVIS_BF16 || d->Cout != 16 || (d->C1 != 16 && d->C1 != 4) || d->C2 != 0 || d->SD != 1) return DEVIS_ERR_UNSUPPORTED;
+  if (d->OD != d->ID || d->OH != d->IH || d->OW != d->IW) return DEVIS_ERR_UNSUPPORTED;
+  if (d->IH * d->IW * 16 >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
+  if (d->OW <= 16) return launch_march<16, 16>(d, x, w, bias, sc, sh, res, y, s);
+  return launch_march<8, 32>(d, x, w, bias, sc, sh, res, y, s);
+}
+
+}  // namespace devis
