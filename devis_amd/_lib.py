@@ -40,8 +40,15 @@ class ConvTDesc(C.Structure):
                 ("KD", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("dtype", C.c_int32)]
 
 
+class EvidParams(C.Structure):
+    _fields_ = [("kind", C.c_int), ("input_kind", C.c_int), ("disentangle", C.c_int),
+                ("lam", C.c_float), ("a_au", C.c_float), ("eps", C.c_float)]
+
+
+CRIT_DCE, CRIT_DCEU, CRIT_CE, CRIT_MSE, CRIT_KL = range(5)
+
 _P, _I64, _I, _F, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
-_CD, _CTD = C.POINTER(ConvDesc), C.POINTER(ConvTDesc)
+_CD, _CTD, _EP = C.POINTER(ConvDesc), C.POINTER(ConvTDesc), C.POINTER(EvidParams)
 
 # name -> (restype, argtypes); every symbol include/devis_hip.h declares
 SIGNATURES = {
@@ -75,6 +82,8 @@ SIGNATURES = {
     "devis_evid_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "devis_evid_loss_fwd": (_I, [_P, _I64, _I64, _I64, _I, _P, _I, _I64, _I64, _I64, _F, _P, _P, _P, _P, _SZ, _P]),
     "devis_evid_loss_bwd": (_I, [_P, _I64, _I64, _I64, _I, _P, _I, _I64, _I64, _I64, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "devis_evid_crit_fwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
+    "devis_evid_crit_bwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devis_evid_infer": (_I, [_P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I, _P]),
     "devis_softplus_bwd": (_I, [_P, _P, _P, _I64, _P]),
 }

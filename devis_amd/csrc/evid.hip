@@ -56,6 +56,14 @@ struct EvidShape {
   int K;
 };
 
+// criterion selector (devis_evid_params.kind) and the per-call constants
+enum { CRIT_DCE = 0, CRIT_DCEU = 1, CRIT_CE = 2, CRIT_MSE = 3, CRIT_KL = 4 };
+struct EvidParams {
+  int raw;         // 0: input = logits (softplus inside); 1: input = alpha (evidence = alpha - 1)
+  int disentangle;
+  float lambda, a_au, eps;
+};
+
 template <typename T>
 __device__ __forceinline__ void load_logits(const T* z, const EvidShape& s, int64_t n, int64_t v, float* out) {
   const T* p = z + n * s.sN + v * s.sV;
@@ -63,11 +71,41 @@ __device__ __forceinline__ void load_logits(const T* z, const EvidShape& s, int6
   for (int k = 0; k < EV_MAXK; ++k) out[k] = k < s.K ? ld(p + k * s.sK) : 0.f;
 }
 
-// ----------------------------------------------------------------- forward
+// e, alpha of one voxel from the input row; ed = the tensor the dice term is taken on
 template <typename T>
+__device__ __forceinline__ void load_voxel(const T* in, const float* ev_in, const EvidShape& s, const EvidParams& p,
+                                           int64_t n, int64_t v, float* zz, float* e, float* al, float* ed) {
+  load_logits<T>(in, s, n, v, zz);
+#pragma unroll
+  for (int k = 0; k < EV_MAXK; ++k) {
+    if (k < s.K) {
+      if (p.raw) { al[k] = zz[k]; e[k] = zz[k] - 1.f; }
+      else { e[k] = softplus_f(zz[k]); al[k] = e[k] + 1.f; }
+      ed[k] = ev_in ? ev_in[(n * s.K + k) * s.V + v] : e[k];
+    } else { e[k] = 0.f; al[k] = 0.f; ed[k] = 0.f; }
+  }
+}
+
+// softmax over the K dice inputs (DiceLoss: exp(log_softmax), criterions.py:176)
+__device__ __forceinline__ void softmax_k(const float* ed, int K, float* prob) {
+  float m = ed[0];
+#pragma unroll
+  for (int k = 1; k < EV_MAXK; ++k) if (k < K) m = fmaxf(m, ed[k]);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < EV_MAXK; ++k) { prob[k] = k < K ? expf(ed[k] - m) : 0.f; sum += prob[k]; }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int k = 0; k < EV_MAXK; ++k) prob[k] *= inv;
+}
+
+// ----------------------------------------------------------------- forward
+// acc[0] = sum of per-voxel terms; acc[1+k], acc[1+MAXK+k], acc[1+2MAXK+k] = the three per-class sums of
+// the dice term: (I, P, R) for the soft dice of CRIT_DCE, (TP, FP, FN) for the Tversky dice of CRIT_DCEU.
+template <typename T, int KIND>
 __global__ void __launch_bounds__(256)
-k_evid_fwd(const T* __restrict__ z, EvidShape s, const void* __restrict__ labels, int ldt, float lambda,
-           float* __restrict__ evidence_out, float* __restrict__ per_voxel_out, double* __restrict__ partial) {
+k_crit_fwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_in, const void* __restrict__ labels, int ldt,
+           EvidParams p, float* __restrict__ evidence_out, float* __restrict__ per_voxel_out, double* __restrict__ partial) {
   const int K = s.K;
   const int64_t NV = s.N * s.V;
   float acc[EV_NACC];
@@ -76,48 +114,108 @@ k_evid_fwd(const T* __restrict__ z, EvidShape s, const void* __restrict__ labels
   const float lgK = lgamma_f((float)K);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NV; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / s.V, v = i % s.V;
-    float zz[EV_MAXK];
-    load_logits<T>(z, s, n, v, zz);
-    const int y = load_label(labels, ldt, i);
-    float S = 0.f, e_y = 0.f, sum_lg = 0.f;
-    float e[EV_MAXK];
+    float zz[EV_MAXK], e[EV_MAXK], al[EV_MAXK], ed[EV_MAXK];
+    load_voxel<T>(in, ev_in, s, p, n, v, zz, e, al, ed);
+    float S = 0.f;
 #pragma unroll
     for (int k = 0; k < EV_MAXK; ++k) {
       if (k < K) {
-        e[k] = softplus_f(zz[k]);
-        S += e[k] + 1.f;
-        if (k == y) e_y = e[k];
+        S += al[k];
         if (evidence_out) evidence_out[(n * K + k) * s.V + v] = e[k];
-      } else {
-        e[k] = 0.f;
       }
     }
-    const float St = S - e_y;            // strength of alpha~ (label class reset to 1)
-    const float psiSt = digamma_f(St);
-    float kl_sum = 0.f;
+    float pv;
+    if (KIND == CRIT_KL) {
+      // KL(Dir(alpha) || Dir(1)), criterions.py:117-127
+      const float psiS = digamma_f(S);
+      float sum_lg = 0.f, kl_sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < EV_MAXK; ++k) {
-      if (k < K && k != y) {
-        const float a = e[k] + 1.f;
-        sum_lg += lgamma_f(a);
-        kl_sum = fmaf(e[k], digamma_f(a) - psiSt, kl_sum);
+      for (int k = 0; k < EV_MAXK; ++k) {
+        if (k < K) {
+          sum_lg += lgamma_f(al[k]);
+          kl_sum = fmaf(al[k] - 1.f, digamma_f(al[k]) - psiS, kl_sum);
+        }
+      }
+      pv = lgamma_f(S) - sum_lg - lgK + kl_sum;
+    } else {
+      const int y = load_label(labels, ldt, i);
+      float e_y = 0.f, a_y = 1.f;
+#pragma unroll
+      for (int k = 0; k < EV_MAXK; ++k) if (k == y) { e_y = e[k]; a_y = al[k]; }
+      const float St = S - e_y;            // strength of alpha~ (label class reset to 1)
+      const float psiSt = digamma_f(St);
+      float sum_lg = 0.f, kl_sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < EV_MAXK; ++k) {
+        if (k < K && k != y) {
+          sum_lg += lgamma_f(al[k]);
+          kl_sum = fmaf(e[k], digamma_f(al[k]) - psiSt, kl_sum);
+        }
+      }
+      const float kl = lgamma_f(St) - sum_lg - lgK + kl_sum;
+      if (KIND == CRIT_MSE) {
+        // criterions.py:144-154: sum (label - alpha/S)^2 + sum alpha(S-alpha)/(S^2 (S+1))
+        float A = 0.f, B = 0.f;
+        const float den = S * S * (S + 1.f);
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) {
+          if (k < K) {
+            const float d = (k == y ? 1.f : 0.f) - al[k] / S;
+            A = fmaf(d, d, A);
+            B += al[k] * (S - al[k]) / den;
+          }
+        }
+        pv = (A + B) + p.lambda * kl;
+      } else {
+        pv = fmaf(p.lambda, kl, digamma_f(S) - digamma_f(a_y));
+      }
+      if (KIND == CRIT_DCE) {
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) {
+          if (k < K) {
+            const bool hit = (k == y);
+            acc[1 + k] += hit ? ed[k] : 0.f;              // I_k
+            acc[1 + EV_MAXK + k] += ed[k];                // P_k
+            acc[1 + 2 * EV_MAXK + k] += hit ? 1.f : 0.f;  // R_k
+          }
+        }
+      }
+      if (KIND == CRIT_DCEU) {
+        // accuracy-vs-uncertainty term, criterions.py:397-411: score = max_k alpha_k/S (first max), u = K/S
+        float score = -1.f;
+        int cls = 0;
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) {
+          if (k < K) { const float pk = al[k] / S; if (pk > score) { score = pk; cls = k; } }
+        }
+        const float u = (float)K / S;
+        float l_au;
+        if (cls == y) {
+          const float t = p.disentangle ? -logf(score * (1.f - u) + p.eps) : -score * logf(1.f - u + p.eps);
+          l_au = p.a_au * t;
+        } else {
+          const float t = p.disentangle ? -logf((1.f - score) * u + p.eps) : -(1.f - score) * logf(u + p.eps);
+          l_au = (1.f - p.a_au) * t;
+        }
+        pv += l_au;
+        // Tversky dice sums on softmax(evidence), criterions.py:166-215; class_mask = 1e-8 with 1 at the label
+        float prob[EV_MAXK];
+        softmax_k(ed, K, prob);
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) {
+          if (k < K) {
+            const float m = (k == y) ? 1.f : 1e-8f;
+            acc[1 + k] = fmaf(prob[k], m, acc[1 + k]);                               // TP_k
+            acc[1 + EV_MAXK + k] = fmaf(prob[k], 1.f - m, acc[1 + EV_MAXK + k]);     // FP_k
+            acc[1 + 2 * EV_MAXK + k] = fmaf(1.f - prob[k], m, acc[1 + 2 * EV_MAXK + k]);  // FN_k
+          }
+        }
       }
     }
-    const float l_ace = digamma_f(S) - digamma_f(e_y + 1.f);
-    const float kl = lgamma_f(St) - sum_lg - lgK + kl_sum;
-    const float pv = fmaf(lambda, kl, l_ace);
     if (per_voxel_out) per_voxel_out[i] = pv;
     acc[0] += pv;
-#pragma unroll
-    for (int k = 0; k < EV_MAXK; ++k) {
-      if (k < K) {
-        const bool hit = (k == y);
-        acc[1 + k] += hit ? e[k] : 0.f;            // I_k
-        acc[1 + EV_MAXK + k] += e[k];              // P_k
-        acc[1 + 2 * EV_MAXK + k] += hit ? 1.f : 0.f;  // R_k
-      }
-    }
   }
+  if (!partial) return;
   __shared__ double red[4][EV_NACC];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -131,7 +229,28 @@ k_evid_fwd(const T* __restrict__ z, EvidShape s, const void* __restrict__ labels
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void k_evid_finalize(const double* __restrict__ partial, int blocks, int K, double NV, float* __restrict__ scal) {
+// Tversky dice of DiceLoss (criterions.py:195-215) and its derivatives w.r.t. the three sums
+struct Tversky { double dice, gTP, gFP, gFN; };
+__host__ __device__ inline Tversky tversky(double TP, double FP, double FN) {
+  const double sm = 1e-5;
+  const double q = FP + FN + sm;
+  double A = FP / q;
+  double dA_dFP = (FN + sm) / (q * q), dA_dFN = -FP / (q * q);
+  if (A < 0.2) { A = 0.2; dA_dFP = 0.0; dA_dFN = 0.0; }
+  if (A > 0.8) { A = 0.8; dA_dFP = 0.0; dA_dFN = 0.0; }
+  const double den = TP + A * FP + (1.0 - A) * FN;
+  const double dd = den + sm;
+  Tversky t;
+  t.dice = TP / dd;
+  // L_k = 1 - TP/dd
+  t.gTP = -(dd - TP) / (dd * dd);
+  t.gFP = TP * (A + (FP - FN) * dA_dFP) / (dd * dd);
+  t.gFN = TP * ((1.0 - A) + (FP - FN) * dA_dFN) / (dd * dd);
+  return t;
+}
+
+__global__ void k_evid_finalize(const double* __restrict__ partial, int blocks, int K, double NV, int kind, float a_au,
+                                float* __restrict__ scal) {
   // 256 threads: accumulator i = tid % 32, block slice = tid / 32; slices combined in a fixed order
   __shared__ double tot[EV_NACC];
   __shared__ double red[8][32];
@@ -152,15 +271,17 @@ __global__ void k_evid_finalize(const double* __restrict__ partial, int blocks, 
   if (threadIdx.x == 0) {
     double dice = 0.0;
     for (int k = 0; k < K; ++k) {
-      const double I = tot[1 + k], P = tot[1 + EV_MAXK + k], R = tot[1 + 2 * EV_MAXK + k];
-      dice += -log((2.0 * I + 1e-5) / (R + P + 1.0 + 1e-5));
-      scal[4 + k] = (float)I;
-      scal[4 + K + k] = (float)P;
-      scal[4 + 2 * K + k] = (float)R;
+      const double s0 = tot[1 + k], s1 = tot[1 + EV_MAXK + k], s2 = tot[1 + 2 * EV_MAXK + k];
+      if (kind == CRIT_DCE) dice += -log((2.0 * s0 + 1e-5) / (s2 + s1 + 1.0 + 1e-5));
+      if (kind == CRIT_DCEU) dice += 1.0 - tversky(s0, s1, s2).dice;
+      scal[4 + k] = (float)s0;
+      scal[4 + K + k] = (float)s1;
+      scal[4 + 2 * K + k] = (float)s2;
     }
     dice /= (double)K;
     const double mean_pv = tot[0] / NV;
-    scal[0] = (float)(mean_pv + dice);
+    const double wd = kind == CRIT_DCEU ? 1.0 - (double)a_au : 1.0;     // criterions.py:417
+    scal[0] = (float)(mean_pv + wd * dice);
     scal[1] = (float)dice;
     scal[2] = (float)mean_pv;
     scal[3] = (float)NV;
@@ -168,52 +289,144 @@ __global__ void k_evid_finalize(const double* __restrict__ partial, int blocks, 
 }
 
 // ---------------------------------------------------------------- backward
-template <typename T>
+// d_in = d loss / d input (logits: chain through softplus; alpha in raw mode).  In raw mode with a
+// separate dice tensor, the dice term's gradient goes to d_ev_in instead.
+template <typename T, int KIND>
 __global__ void __launch_bounds__(256)
-k_evid_bwd(const T* __restrict__ z, EvidShape s, const void* __restrict__ labels, int ldt, float lambda,
-           const float* __restrict__ scal, const float* __restrict__ grad_loss, const float* __restrict__ grad_pv,
-           const float* __restrict__ grad_dice, const float* __restrict__ grad_ev, T* __restrict__ dz) {
+k_crit_bwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_in, const void* __restrict__ labels, int ldt,
+           EvidParams p, const float* __restrict__ scal, const float* __restrict__ grad_loss,
+           const float* __restrict__ grad_pv, const float* __restrict__ grad_dice, const float* __restrict__ grad_ev,
+           T* __restrict__ d_in, float* __restrict__ d_ev_in) {
   const int K = s.K;
   const int64_t NV = s.N * s.V;
-  // dice coefficients: dL_dice/de_k(v) = cD_k - [y=k]*cI_k
-  float cI[EV_MAXK], cD[EV_MAXK];
-  const float gd = grad_pv ? (grad_dice ? grad_dice[0] : 0.f) : grad_loss[0];
+  // dice coefficients.  CRIT_DCE: dL/de_k(v) = c1_k - [y=k]*c0_k.   CRIT_DCEU: dL/dprob_k(v) = [y=k] ? c0_k : c1_k.
+  float c0[EV_MAXK], c1[EV_MAXK];
+  float gd = 0.f;
+  if (KIND == CRIT_DCE || KIND == CRIT_DCEU) {
+    if (grad_pv) gd = grad_dice ? grad_dice[0] : 0.f;
+    else gd = grad_loss[0] * (KIND == CRIT_DCEU ? 1.f - p.a_au : 1.f);
+  }
   const float gmean = grad_pv ? 0.f : grad_loss[0] / (float)NV;
 #pragma unroll
   for (int k = 0; k < EV_MAXK; ++k) {
-    if (k < K) {
+    c0[k] = 0.f; c1[k] = 0.f;
+    if (k < K && KIND == CRIT_DCE) {
       const float I = scal[4 + k], P = scal[4 + K + k], R = scal[4 + 2 * K + k];
-      cI[k] = gd * 2.f / ((2.f * I + 1e-5f) * (float)K);
-      cD[k] = gd / ((R + P + 1.f + 1e-5f) * (float)K);
-    } else { cI[k] = 0.f; cD[k] = 0.f; }
+      c0[k] = gd * 2.f / ((2.f * I + 1e-5f) * (float)K);
+      c1[k] = gd / ((R + P + 1.f + 1e-5f) * (float)K);
+    }
+    if (k < K && KIND == CRIT_DCEU) {
+      const Tversky t = tversky((double)scal[4 + k], (double)scal[4 + K + k], (double)scal[4 + 2 * K + k]);
+      const double w = (double)gd / (double)K;
+      c0[k] = (float)(w * (t.gTP - t.gFN));                            // mask = 1: tp and fn rows
+      c1[k] = (float)(w * (t.gTP * 1e-8 + t.gFP * (double)(1.f - 1e-8f) - t.gFN * 1e-8));
+    }
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NV; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / s.V, v = i % s.V;
-    float zz[EV_MAXK];
-    load_logits<T>(z, s, n, v, zz);
-    const int y = load_label(labels, ldt, i);
-    float e[EV_MAXK];
-    float S = 0.f, e_y = 0.f;
+    float zz[EV_MAXK], e[EV_MAXK], al[EV_MAXK], ed[EV_MAXK];
+    load_voxel<T>(in, ev_in, s, p, n, v, zz, e, al, ed);
+    float S = 0.f;
 #pragma unroll
-    for (int k = 0; k < EV_MAXK; ++k) {
-      e[k] = k < K ? softplus_f(zz[k]) : 0.f;
-      if (k < K) S += e[k] + 1.f;
-      if (k == y) e_y = e[k];
-    }
-    const float St = S - e_y;
-    const float tS = trigamma_f(S);
-    const float tSt = trigamma_f(St) * (St - (float)K);
+    for (int k = 0; k < EV_MAXK; ++k) if (k < K) S += al[k];
     const float g = grad_pv ? grad_pv[i] : gmean;
-    T* out = dz + n * s.sN + v * s.sV;
+    float d[EV_MAXK], dd[EV_MAXK];
+#pragma unroll
+    for (int k = 0; k < EV_MAXK; ++k) { d[k] = 0.f; dd[k] = 0.f; }
+    const float tS = trigamma_f(S);
+    if (KIND == CRIT_KL) {
+      const float tail = tS * (S - (float)K);
+#pragma unroll
+      for (int k = 0; k < EV_MAXK; ++k)
+        if (k < K) d[k] = g * fmaf(al[k] - 1.f, trigamma_f(al[k]), -tail);
+    } else {
+      const int y = load_label(labels, ldt, i);
+      float e_y = 0.f;
+#pragma unroll
+      for (int k = 0; k < EV_MAXK; ++k) if (k == y) e_y = e[k];
+      const float St = S - e_y;
+      const float tSt = trigamma_f(St) * (St - (float)K);
+      if (KIND == CRIT_MSE) {
+        // A = sum (l - m)^2, m = alpha/S;  B = (S^2 - Q)/(S^3 + S^2), Q = sum alpha^2
+        float Q = 0.f, cross = 0.f;
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) {
+          if (k < K) {
+            const float m = al[k] / S;
+            Q = fmaf(al[k], al[k], Q);
+            cross = fmaf((k == y ? 1.f : 0.f) - m, m, cross);
+          }
+        }
+        const float D = S * S * (S + 1.f);
+        const float dD = 3.f * S * S + 2.f * S;
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) {
+          if (k < K) {
+            const float m = al[k] / S;
+            const float dA = -2.f / S * (((k == y ? 1.f : 0.f) - m) - cross);
+            const float dB = ((2.f * S - 2.f * al[k]) * D - (S * S - Q) * dD) / (D * D);
+            const float dk = (k == y) ? 0.f : p.lambda * fmaf(e[k], trigamma_f(al[k]), -tSt);
+            d[k] = g * (dA + dB + dk);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) {
+          if (k < K) {
+            const float ta = trigamma_f(al[k]);
+            d[k] = g * ((k == y) ? (tS - ta) : fmaf(p.lambda, fmaf(e[k], ta, -tSt), tS));
+          }
+        }
+      }
+      if (KIND == CRIT_DCE) {
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) if (k < K) dd[k] = c1[k] - ((k == y) ? c0[k] : 0.f);
+      }
+      if (KIND == CRIT_DCEU) {
+        float score = -1.f;
+        int cls = 0;
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) {
+          if (k < K) { const float pk = al[k] / S; if (pk > score) { score = pk; cls = k; } }
+        }
+        const float u = (float)K / S;
+        const float du = -u / S;                       // d u / d alpha_k (every k)
+        // f = w * t(score, u): df/dalpha_k = w * (t_s * dscore_k + t_u * du), dscore_k = ([k=cls] - score)/S
+        float w, t_s, t_u;
+        if (cls == y) {
+          w = p.a_au;
+          if (p.disentangle) { const float q = score * (1.f - u) + p.eps; t_s = -(1.f - u) / q; t_u = score / q; }
+          else { const float q = 1.f - u + p.eps; t_s = -logf(q); t_u = score / q; }
+        } else {
+          w = 1.f - p.a_au;
+          if (p.disentangle) { const float q = (1.f - score) * u + p.eps; t_s = u / q; t_u = -(1.f - score) / q; }
+          else { const float q = u + p.eps; t_s = logf(q); t_u = -(1.f - score) / q; }
+        }
+        const float gw = g * w;
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k)
+          if (k < K) d[k] += gw * fmaf(t_s, ((k == cls ? 1.f : 0.f) - score) / S, t_u * du);
+        float prob[EV_MAXK];
+        softmax_k(ed, K, prob);
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) if (k < K) dot = fmaf(prob[k], (k == y) ? c0[k] : c1[k], dot);
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) if (k < K) dd[k] = prob[k] * (((k == y) ? c0[k] : c1[k]) - dot);
+      }
+    }
+    T* out = d_in + n * s.sN + v * s.sV;
 #pragma unroll
     for (int k = 0; k < EV_MAXK; ++k) {
       if (k < K) {
-        const float a = e[k] + 1.f;
-        const float ta = trigamma_f(a);
-        float d = (k == y) ? (tS - ta) : fmaf(lambda, fmaf(e[k], ta, -tSt), tS);
-        d = fmaf(g, d, cD[k] - ((k == y) ? cI[k] : 0.f));
-        if (grad_ev) d += grad_ev[(n * K + k) * s.V + v];
-        st(out + k * s.sK, d * dsoftplus_f(zz[k]));
+        float r = d[k];
+        if (d_ev_in) d_ev_in[(n * K + k) * s.V + v] = dd[k];
+        else r += dd[k];
+        if (!p.raw) {
+          if (grad_ev) r += grad_ev[(n * K + k) * s.V + v];
+          r *= dsoftplus_f(zz[k]);
+        }
+        st(out + k * s.sK, r);
       }
     }
   }
@@ -289,32 +502,74 @@ size_t devis_evid_workspace_bytes(int64_t N, int64_t V, int64_t K) {
   return (size_t)EV_BLOCKS * EV_NACC * sizeof(double);
 }
 
+static bool crit_args_ok(const devis_evid_params* p, const void* in, const void* labels, int label_dtype, int64_t N,
+                         int64_t V, int64_t K) {
+  if (!p || !in || N <= 0 || V <= 0 || K < 2 || K > EV_MAXK) return false;
+  if (p->kind < 0 || p->kind > CRIT_KL || (p->input_kind != 0 && p->input_kind != 1)) return false;
+  if (p->kind != CRIT_KL && (!labels || label_dtype < 0 || label_dtype > 2)) return false;
+  return true;
+}
+
+#define DEVIS_DISPATCH_KIND(kind, ...)                                              \
+  switch (kind) {                                                                   \
+    case CRIT_DCE: { constexpr int KIND = CRIT_DCE; __VA_ARGS__; } break;           \
+    case CRIT_DCEU: { constexpr int KIND = CRIT_DCEU; __VA_ARGS__; } break;         \
+    case CRIT_CE: { constexpr int KIND = CRIT_CE; __VA_ARGS__; } break;             \
+    case CRIT_MSE: { constexpr int KIND = CRIT_MSE; __VA_ARGS__; } break;           \
+    default: { constexpr int KIND = CRIT_KL; __VA_ARGS__; } break;                  \
+  }
+
+int devis_evid_crit_fwd(const devis_evid_params* p, const void* in, int64_t sN, int64_t sV, int64_t sK, int dtype,
+                        const float* evidence_in, const void* labels, int label_dtype, int64_t N, int64_t V, int64_t K,
+                        float* evidence_out, float* per_voxel_out, float* scal, void* ws, size_t ws_bytes, void* stream) {
+  if (!crit_args_ok(p, in, labels, label_dtype, N, V, K)) return DEVIS_ERR_BAD_ARG;
+  if (!scal && !per_voxel_out) return DEVIS_ERR_BAD_ARG;
+  if (scal && (!ws || ws_bytes < devis_evid_workspace_bytes(N, V, K))) return ws ? DEVIS_ERR_WORKSPACE : DEVIS_ERR_BAD_ARG;
+  if (evidence_in && !p->input_kind) return DEVIS_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const EvidShape sh = {sN, sV, sK, N, V, (int)K};
+  const EvidParams ep = {p->input_kind, p->disentangle, p->lambda, p->a_au, p->eps};
+  const unsigned blocks = ev_grid(N * V);
+  double* part = scal ? (double*)ws : nullptr;
+  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, hipLaunchKernelGGL((k_crit_fwd<T, KIND>), dim3(blocks), dim3(256), 0, s, (const T*)in, sh, evidence_in, labels, label_dtype, ep, evidence_out, per_voxel_out, part)));
+  int rc = launch_status();
+  if (rc || !scal) return rc;
+  hipLaunchKernelGGL(k_evid_finalize, dim3(1), dim3(256), 0, s, (const double*)ws, (int)blocks, (int)K, (double)(N * V), p->kind, p->a_au, scal);
+  return launch_status();
+}
+
+int devis_evid_crit_bwd(const devis_evid_params* p, const void* in, int64_t sN, int64_t sV, int64_t sK, int dtype,
+                        const float* evidence_in, const void* labels, int label_dtype, int64_t N, int64_t V, int64_t K,
+                        const float* scal, const float* grad_loss, const float* grad_pv, const float* grad_dice,
+                        const float* grad_ev, void* d_in, float* d_evidence_in, void* stream) {
+  if (!crit_args_ok(p, in, labels, label_dtype, N, V, K) || !d_in) return DEVIS_ERR_BAD_ARG;
+  if (!grad_loss && !grad_pv) return DEVIS_ERR_BAD_ARG;
+  const bool has_dice = p->kind == CRIT_DCE || p->kind == CRIT_DCEU;
+  if (has_dice && !scal) return DEVIS_ERR_BAD_ARG;
+  if ((evidence_in != nullptr) != (d_evidence_in != nullptr)) return DEVIS_ERR_BAD_ARG;
+  if (evidence_in && (!p->input_kind || !has_dice)) return DEVIS_ERR_BAD_ARG;
+  const EvidShape sh = {sN, sV, sK, N, V, (int)K};
+  const EvidParams ep = {p->input_kind, p->disentangle, p->lambda, p->a_au, p->eps};
+  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, hipLaunchKernelGGL((k_crit_bwd<T, KIND>), dim3(ev_grid(N * V)), dim3(256), 0, (hipStream_t)stream, (const T*)in, sh, evidence_in, labels, label_dtype, ep, scal, grad_loss, grad_pv, grad_dice, grad_ev, (T*)d_in, d_evidence_in)));
+  return launch_status();
+}
+
 int devis_evid_loss_fwd(const void* logits, int64_t sN, int64_t sV, int64_t sK, int dtype, const void* labels,
                         int label_dtype, int64_t N, int64_t V, int64_t K, float lambda, float* evidence_out,
                         float* per_voxel_out, float* scal, void* ws, size_t ws_bytes, void* stream) {
-  if (!logits || !labels || !scal || !ws || N <= 0 || V <= 0 || K < 2 || K > EV_MAXK) return DEVIS_ERR_BAD_ARG;
-  if (label_dtype < 0 || label_dtype > 2) return DEVIS_ERR_BAD_ARG;
-  if (ws_bytes < devis_evid_workspace_bytes(N, V, K)) return DEVIS_ERR_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
-  const EvidShape sh = {sN, sV, sK, N, V, (int)K};
-  const unsigned blocks = ev_grid(N * V);
-  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_evid_fwd<T>, dim3(blocks), dim3(256), 0, s, (const T*)logits, sh, labels, label_dtype, lambda, evidence_out, per_voxel_out, (double*)ws));
-  int rc = launch_status();
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_evid_finalize, dim3(1), dim3(256), 0, s, (const double*)ws, (int)blocks, (int)K, (double)(N * V), scal);
-  return launch_status();
+  if (!scal) return DEVIS_ERR_BAD_ARG;
+  const devis_evid_params p = {CRIT_DCE, 0, 0, lambda, 0.f, 0.f};
+  return devis_evid_crit_fwd(&p, logits, sN, sV, sK, dtype, nullptr, labels, label_dtype, N, V, K, evidence_out,
+                             per_voxel_out, scal, ws, ws_bytes, stream);
 }
 
 int devis_evid_loss_bwd(const void* logits, int64_t sN, int64_t sV, int64_t sK, int dtype, const void* labels,
                         int label_dtype, int64_t N, int64_t V, int64_t K, float lambda, const float* scal,
                         const float* grad_loss, const float* grad_pv, const float* grad_dice, const float* grad_ev,
                         void* dlogits, void* stream) {
-  if (!logits || !labels || !scal || !dlogits || N <= 0 || V <= 0 || K < 2 || K > EV_MAXK) return DEVIS_ERR_BAD_ARG;
-  if (!grad_loss && !grad_pv) return DEVIS_ERR_BAD_ARG;
-  if (label_dtype < 0 || label_dtype > 2) return DEVIS_ERR_BAD_ARG;
-  const EvidShape sh = {sN, sV, sK, N, V, (int)K};
-  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_evid_bwd<T>, dim3(ev_grid(N * V)), dim3(256), 0, (hipStream_t)stream, (const T*)logits, sh, labels, label_dtype, lambda, scal, grad_loss, grad_pv, grad_dice, grad_ev, (T*)dlogits));
-  return launch_status();
+  const devis_evid_params p = {CRIT_DCE, 0, 0, lambda, 0.f, 0.f};
+  return devis_evid_crit_bwd(&p, logits, sN, sV, sK, dtype, nullptr, labels, label_dtype, N, V, K, scal, grad_loss,
+                             grad_pv, grad_dice, grad_ev, dlogits, nullptr, stream);
 }
 
 int devis_evid_infer(const void* logits, int64_t sN, int64_t sV, int64_t sK, int dtype, int64_t N, int64_t V, int64_t K,

@@ -419,6 +419,49 @@ def evid_loss_bwd(logits: Tensor, channels_last: bool, labels: Tensor, lam: floa
     return dz
 
 
+def crit_params(kind: int, raw: bool, lam: float = 0.0, a_au: float = 0.0, eps: float = 0.0,
+                disentangle: bool = False) -> "_lib.EvidParams":
+    return _lib.EvidParams(int(kind), 1 if raw else 0, 1 if disentangle else 0, float(lam), float(a_au), float(eps))
+
+
+def crit_fwd(params, x: Tensor, strides, labels: Optional[Tensor], evidence_in: Optional[Tensor] = None,
+             want_evidence: bool = False, want_per_voxel: bool = True, want_scal: bool = True, ev_shape=None):
+    """General evidential criterion forward (devis_evid_crit_fwd).  `strides` = (N, V, K, sN, sV, sK) of x."""
+    _need_cuda(x, labels, evidence_in)
+    n, v, k, sn, sv, sk = strides
+    if labels is not None and labels.numel() != n * v:
+        raise _lib.DevisError("labels must hold one class index per voxel")
+    if evidence_in is not None and (evidence_in.dtype != torch.float32 or evidence_in.numel() != n * v * k):
+        raise _lib.DevisError("evidence must be fp32 with the shape of alpha")
+    f = dict(dtype=torch.float32, device=x.device)
+    evidence = torch.empty(ev_shape if ev_shape is not None else (n, k, v), **f) if want_evidence else None
+    per_voxel = torch.empty((n * v, 1), **f) if want_per_voxel else None
+    scal = torch.empty((_lib.EVID_SCAL_FLOATS,), **f) if want_scal else None
+    lib = _lib.load()
+    nb = lib.devis_evid_workspace_bytes(n, v, k) if want_scal else 0
+    ws = workspace(nb, x.device) if want_scal else None
+    check(lib.devis_evid_crit_fwd(C.byref(params), _p(x), sn, sv, sk, dt_code(x.dtype), _p(evidence_in), _p(labels),
+                                  _label_code(labels) if labels is not None else 0, n, v, k, _p(evidence),
+                                  _p(per_voxel), _p(scal), _p(ws), nb, _stream()), "evid_crit_fwd")
+    return scal, evidence, per_voxel
+
+
+def crit_bwd(params, x: Tensor, strides, labels: Optional[Tensor], scal: Optional[Tensor],
+             evidence_in: Optional[Tensor] = None, grad_loss: Optional[Tensor] = None,
+             grad_per_voxel: Optional[Tensor] = None, grad_dice: Optional[Tensor] = None,
+             grad_evidence: Optional[Tensor] = None):
+    """-> (d_x, d_evidence_in | None)"""
+    _need_cuda(x, labels, scal, evidence_in, grad_loss, grad_per_voxel, grad_dice, grad_evidence)
+    n, v, k, sn, sv, sk = strides
+    dx = torch.empty_like(x)
+    dev = torch.empty_like(evidence_in) if evidence_in is not None else None
+    check(_lib.load().devis_evid_crit_bwd(C.byref(params), _p(x), sn, sv, sk, dt_code(x.dtype), _p(evidence_in),
+                                          _p(labels), _label_code(labels) if labels is not None else 0, n, v, k,
+                                          _p(scal), _p(grad_loss), _p(grad_per_voxel), _p(grad_dice),
+                                          _p(grad_evidence), _p(dx), _p(dev), _stream()), "evid_crit_bwd")
+    return dx, dev
+
+
 def evid_infer(logits: Tensor, channels_last: bool, thresholds: Sequence[float] = (), want_evidence: bool = True,
                want_mne: bool = False):
     """-> dict(evidence, pred uint8, u fp32, mne, umask uint16)."""

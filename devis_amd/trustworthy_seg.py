@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .criterions import evidential_head_loss, dce_evidence_u_loss
+from .criterions import evidential_head_loss
 from .predict import tailor_and_concat
 from .unet2d import Unet2D, Unet2DDRIVE
 from .unet3d import Unet
@@ -63,14 +63,10 @@ class TMSU(nn.Module):
     def forward(self, X, y, global_step, mode, dataset):
         if mode == 'train':
             logits = self.backbone.forward_channels_last(X)
-            if self.u_loss:
-                evidence = self.infer(ops_from_cl(logits))
-                alpha = evidence + 1
-                loss = dce_evidence_u_loss(y.to(torch.int64), alpha, self.classes, global_step, self.lambda_epochs,
-                                           self.total_epochs, self.eps, self.disentangle, evidence, None)
-                return evidence, torch.mean(loss)
             evidence, loss = evidential_head_loss(logits, _labels(y), global_step, self.lambda_epochs,
-                                                  channels_last=True, want_evidence=True)
+                                                  channels_last=True, want_evidence=True, u_loss=bool(self.u_loss),
+                                                  total_step=self.total_epochs, eps=self.eps,
+                                                  disentangle=self.disentangle)
             return evidence, loss
         if dataset == 'BraTS':
             out = tailor_and_concat(X, self.backbone)

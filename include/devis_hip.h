@@ -187,6 +187,40 @@ int devis_evid_loss_bwd(const void* logits, int64_t sN, int64_t sV, int64_t sK, 
                         float lambda, const float* scal, const float* grad_loss,
                         const float* grad_per_voxel, const float* grad_dice,
                         const float* grad_evidence, void* dlogits, void* stream);
+/* General form of the two calls above, covering every evidential criterion of models/criterions.py.
+ *   kind  DEVIS_CRIT_DCE   dce_evidence_loss     criterions.py:421-456 (soft dice on the evidence)
+ *         DEVIS_CRIT_DCEU  dce_evidence_u_loss   criterions.py:373-419 + DiceLoss :166-215 (Tversky dice on
+ *                          softmax(evidence), accuracy-vs-uncertainty term with a_au, eps, disentangle)
+ *         DEVIS_CRIT_CE    ce_loss               criterions.py:130-142   (per voxel only)
+ *         DEVIS_CRIT_MSE   mse_loss              criterions.py:144-154   (per voxel only)
+ *         DEVIS_CRIT_KL    KL(alpha, c)          criterions.py:117-127   (per voxel only, no labels)
+ *   input_kind 0: `in` holds logits (softplus inside, as TMSU.forward :144-146); 1: `in` holds alpha, the
+ *   evidence is alpha - 1 (criterions.py:441) and `evidence_in` (optional, NC(D)HW fp32) is the separate
+ *   tensor the dice term is taken on (the `evidence` argument of the reference functions).
+ * per_voxel_out [N*V] = the criterion's (NV,1) result without the broadcast dice term; scal as above with
+ *   [0] = mean(per voxel) + w * L_dice (w = 1, or 1 - a_au for DCEU), and for DCEU [4..] = TP_k, FP_k, FN_k.
+ *   scal (with workspace) may be NULL when only per_voxel_out is wanted.
+ * bwd: d_in (strides/dtype of `in`) = gradient w.r.t. logits or alpha; d_evidence_in (NC(D)HW fp32, iff
+ *   evidence_in was given) = the dice term's gradient w.r.t. that tensor.  grad_* as devis_evid_loss_bwd. */
+enum { DEVIS_CRIT_DCE = 0, DEVIS_CRIT_DCEU = 1, DEVIS_CRIT_CE = 2, DEVIS_CRIT_MSE = 3, DEVIS_CRIT_KL = 4 };
+typedef struct devis_evid_params {
+  int kind;
+  int input_kind;
+  int disentangle;
+  float lambda; /* KL annealing coefficient min(1, step / lambda_step) */
+  float a_au;   /* DCEU: 0.01 * exp(-ln(0.01) * step / total_step), criterions.py:392-393 */
+  float eps;    /* DCEU */
+} devis_evid_params;
+int devis_evid_crit_fwd(const devis_evid_params* p, const void* in, int64_t sN, int64_t sV, int64_t sK,
+                        int dtype, const float* evidence_in, const void* labels, int label_dtype,
+                        int64_t N, int64_t V, int64_t K, float* evidence_out, float* per_voxel_out,
+                        float* scal, void* workspace, size_t workspace_bytes, void* stream);
+int devis_evid_crit_bwd(const devis_evid_params* p, const void* in, int64_t sN, int64_t sV, int64_t sK,
+                        int dtype, const float* evidence_in, const void* labels, int label_dtype,
+                        int64_t N, int64_t V, int64_t K, const float* scal, const float* grad_loss,
+                        const float* grad_per_voxel, const float* grad_dice, const float* grad_evidence,
+                        void* d_in, float* d_evidence_in, void* stream);
+
 /* val/test head (trainUMIS.py:286-290,446-451,521; predict.py:92-105):
  *   evidence (optional, NC(D)HW fp32), pred = argmax_k alpha_k/S (first max; uint8),
  *   u = K/S (fp32), mne = normalised entropy over classes >= 1 (optional fp32),
