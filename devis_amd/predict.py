@@ -42,3 +42,55 @@ def tailor_and_concat(x, model):
         dst, src = patch_regions(i)
         y[(Ellipsis,) + dst] = out[(Ellipsis,) + src]
     return y[..., :155]
+
+
+def _default_head(backbone, thresholds, want_evidence, want_mne):
+    """patch (1,C,128,128,128) -> dict of per-voxel maps for the patch: backbone + fused inference head on the
+    channels-last logits (no NCDHW copy of the logits is ever made)."""
+    from . import ops
+
+    def run(patch):
+        logits = backbone.forward_channels_last(patch)
+        return ops.evid_infer(logits, True, thresholds, want_evidence=want_evidence, want_mne=want_mne)
+    return run
+
+
+def sliding_window_infer(x, backbone, thresholds=(), rank: int = 0, world: int = 1, group=None,
+                         want_evidence: bool = False, want_mne: bool = True, patch_fn=None):
+    """Sharded form of the BraTS val/test forward (predict.py:159-191 + trainUMIS.py:286-290,446-461,521):
+    patch i runs on rank i % world, each rank applies the fused inference head to its own
+    patches and writes their kept sub-regions into zero-initialised volume maps; the regions are disjoint, so
+    one SUM all-reduce per map assembles the volume on every rank (no collective when world == 1).
+
+    Returns dict(pred uint8 (1,240,240,155), u fp32 (1,1,...), mne fp32, umask int16, evidence fp32 (1,K,...))
+    with the entries that were asked for.  `patch_fn(patch) -> dict` replaces backbone + head (tests).
+    """
+    from .parallel import shard_patches
+    run = patch_fn if patch_fn is not None else _default_head(backbone, thresholds, want_evidence, want_mne)
+    vol = tuple(x.shape[2:4]) + (155,)
+    out = {}
+    for i in shard_patches(len(CROPS), rank, world):
+        maps = run(crop(x, i))
+        dst, src = patch_regions(i)
+        for key, t in maps.items():
+            if t is None:
+                continue
+            if key not in out:
+                lead = tuple(t.shape[:t.dim() - 3])
+                out[key] = torch.zeros(lead + vol, dtype=t.dtype, device=t.device)
+            out[key][(Ellipsis,) + dst] = t[(Ellipsis,) + src]
+    if world > 1:
+        import torch.distributed as dist
+        keys = sorted(out)                       # same order on every rank (every rank owns >= 1 patch iff world <= 8)
+        if len(shard_patches(len(CROPS), rank, world)) == 0:
+            raise ValueError("sliding_window_infer: more ranks than patches (world must be <= 8)")
+        for key in keys:
+            t = out[key]
+            # disjoint supports: SUM == placement.  Integer maps go through int32 (exact; gloo has no int16 sum)
+            if t.dtype in (torch.uint8, torch.int16):
+                w = t.to(torch.int32)
+                dist.all_reduce(w, op=dist.ReduceOp.SUM, group=group)
+                out[key] = w.to(t.dtype)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return out

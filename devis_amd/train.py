@@ -118,8 +118,14 @@ def predict_volume(model, x, dataset, thresholds=()):
     u = K/S, normalised entropy, u-threshold masks - one fused kernel after the backbone."""
     model.eval()
     with torch.no_grad():
-        from .predict import tailor_and_concat
-        logits = tailor_and_concat(x, model.backbone) if dataset == 'BraTS' else model.backbone(x)
+        if dataset == 'BraTS':
+            # eight patches, sharded over the ranks when torch.distributed is up (SURVEY.md §8e)
+            import torch.distributed as dist
+            from .predict import sliding_window_infer
+            on = dist.is_available() and dist.is_initialized()
+            rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+            return sliding_window_infer(x, model.backbone, thresholds, rank, world, want_evidence=True, want_mne=True)
+        logits = model.backbone(x)
         return ops.evid_infer(logits.contiguous(), False, thresholds, want_evidence=True, want_mne=True)
 
 

@@ -44,3 +44,45 @@ def test_tmsu_val_mode_matches_oracle_on_one_patch():
         ref = torch.nn.functional.softplus(O.unet3d_forward(sd, x[..., :128, :128, :128][..., :64].contiguous()
                                                             if False else x[..., :128, :128, :128], False))
     assert rel_err(ev[..., :128, :128, :128], ref) < 5e-5
+
+
+def test_sliding_window_infer_equals_stitch_then_head():
+    """Fused per-patch head on channels-last logits + region placement == tailor_and_concat of NCDHW logits
+    followed by the head (the reference's order, trainUMIS.py:283-290): bit-exact, also when the patches
+    are split between two (emulated) ranks and the maps are summed."""
+    from oracle.devis_oracle import UNCERTAINTY_THRESHOLDS as THR
+    from devis_amd import TMSU, ops, tailor_and_concat
+    from devis_amd.predict import CROPS, crop, patch_regions, sliding_window_infer
+    from devis_amd.parallel import shard_patches
+    from tests.util import brats_args
+    for dtype in (torch.float32, torch.bfloat16):
+        torch.manual_seed(1)
+        m = TMSU(brats_args(compute_dtype=dtype))
+        m.eval()
+        g = torch.Generator().manual_seed(10)
+        x = torch.randn((1, 4, 240, 240, 160), generator=g).cuda()
+        with torch.no_grad():
+            ref = ops.evid_infer(tailor_and_concat(x, m.backbone).contiguous(), False, THR, want_evidence=True,
+                                 want_mne=True)
+            one = sliding_window_infer(x, m.backbone, THR, want_evidence=True, want_mne=True)
+            # two emulated ranks: each runs its shard only (no process group), then the maps are added
+            halves = []
+            for r in range(2):
+                out = {}
+                for i in shard_patches(len(CROPS), r, 2):
+                    maps = ops.evid_infer(m.backbone.forward_channels_last(crop(x, i)), True, THR, want_evidence=False)
+                    dst, src = patch_regions(i)
+                    for k, t in maps.items():
+                        if t is None:
+                            continue
+                        if k not in out:
+                            out[k] = torch.zeros(tuple(t.shape[:t.dim() - 3]) + (240, 240, 155), dtype=t.dtype, device=t.device)
+                        out[k][(Ellipsis,) + dst] = t[(Ellipsis,) + src]
+                halves.append(out)
+        for k in ("pred", "u", "mne", "umask", "evidence"):
+            assert one[k].shape == ref[k].shape and torch.equal(one[k], ref[k]), (str(dtype), k)
+        for k in ("pred", "u", "umask"):
+            both = halves[0][k].to(torch.int32) + halves[1][k].to(torch.int32) if k != "u" else halves[0][k] + halves[1][k]
+            assert torch.equal(both.to(ref[k].dtype), ref[k]), (str(dtype), k)
+        # supports are disjoint
+        assert int(((halves[0]["u"] != 0) & (halves[1]["u"] != 0)).sum()) == 0
