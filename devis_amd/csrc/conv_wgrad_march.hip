@@ -1,0 +1,291 @@
+// Plane-marching MFMA weight gradient of the 16-channel, full-resolution 3x3x3 convolutions
+// (bf16, channels-last, stride 1, gfx950); the companion of conv_march.hip.
+//
+//   dW[co][tap][ci] = sum_v dy[v][co] * A[v + off(tap)][ci],   A = relu(scale*x + shift)
+//
+// GEMM: M = cout, N = cin, K = voxels.  A block owns an (8 x 32) column and walks it along D with a
+// ring of 4 activation planes (halo included, prologue applied) and a double-buffered dy plane in
+// LDS; plane d+2 of x and plane d+1 of dy are in flight from HBM while plane d is multiplied.
+// Both operands need K (voxels) per lane while memory is channels-last, so both are fetched with
+// the transposing LDS read (ds_read_b64_tr_b16).  Wave w keeps the accumulators of taps w, w+4, ...
+// (7 x 16x16 fp32) for the whole walk; one partial [27][16][16] per block goes to the workspace and
+// k_wgrad_reduce adds the partials in a fixed order (deterministic, no atomics).
+#include "common.h"
+#include "mfma_common.h"
+
+#include <stdlib.h>
+
+namespace devis {
+
+int launch_wgrad_reduce(const float* part, const float* bpart, int gx, int Cout, int Cin, int cin_real, float* dw,
+                        float* dbias, hipStream_t s);
+
+struct WgMarchArgs {
+  const bf16* x;
+  const bf16* dy;
+  const float* sc;   // [N][16] or null
+  const float* sh;
+  float* part;       // [blocks][27][16][16]
+  float* bpart;      // [blocks][16] or null
+  int N, D, H, W;
+  int nth, ntw, ndc, DL;
+};
+
+__device__ __forceinline__ bf16x8 tr_pair_m(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+  union { s16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = a;
+  u.h[1] = b;
+  return u.v;
+}
+
+template <bool PRO, bool CIN4>
+__global__ void __launch_bounds__(256)
+k_wgrad3_c16_march(WgMarchArgs a) {
+  constexpr int TH = 8, TW = 32;
+  constexpr int HH = TH + 2, HW = TW + 2, HP = HH * HW;
+  constexpr int NPT = (HP * 2 + 255) / 256;          // 16-byte pieces of an x plane per thread (3)
+  constexpr int PLB = NPT * 256 * 16;                // bytes per x plane in LDS
+  constexpr int R = 4;
+  constexpr int YPL = TH * TW * 32;                  // bytes per dy plane tile (2 pieces per thread)
+  constexpr int CINR = CIN4 ? 4 : 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ys = smem + R * PLB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int qq = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
+  }
+  const int twi = tile % a.ntw;
+  const int thi = (tile / a.ntw) % a.nth;
+  const int dci = (tile / (a.ntw * a.nth)) % a.ndc;
+  const int n = tile / (a.ntw * a.nth * a.ndc);
+  const int oh0 = thi * TH, ow0 = twi * TW;
+  const int d0 = dci * a.DL;
+  const int d1 = min(d0 + a.DL, a.D);
+  const size_t plane = (size_t)a.H * a.W;
+
+  // ---- per-thread load slots: x halo plane (3 pieces) and dy plane tile (2 pieces)
+  unsigned goff[NPT];
+  bool ok[NPT];
+  const int piece = tid & 1;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int i = tid + k * 256;
+    const int u = i >> 1;
+    const int hh = u / HW, hw = u - hh * HW;
+    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+    ok[k] = i < HP * 2 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && !(CIN4 && piece);
+    goff[k] = ok[k] ? (unsigned)((ih * a.W + iw) * CINR + (CIN4 ? 0 : piece * 8)) : 0u;
+  }
+  unsigned yoff[2];
+  bool yok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = (tid + k * 256) >> 1;               // voxel of the 8x32 tile, row-major
+    const int oh = oh0 + v / TW, ow = ow0 + v % TW;
+    yok[k] = oh < a.H && ow < a.W;
+    yoff[k] = yok[k] ? (unsigned)((oh * a.W + ow) * 16 + piece * 8) : 0u;
+  }
+  float scv[8], shv[8];
+  if (PRO) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      scv[j] = a.sc[n * 16 + piece * 8 + j];
+      shv[j] = a.sh[n * 16 + piece * 8 + j];
+    }
+  }
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+  auto load_x = [&](int id, uint4 (&rg)[NPT]) {
+    const int idc = min(max(id, 0), a.D - 1);
+    const bf16* xp = a.x + ((size_t)n * a.D + idc) * plane * CINR;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      if (CIN4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(xp + goff[k]);
+        rg[k] = make_uint4(t.x, t.y, 0u, 0u);
+      } else {
+        rg[k] = *reinterpret_cast<const uint4*>(xp + goff[k]);
+      }
+    }
+  };
+  auto store_x = [&](int id, int slot, uint4 (&rg)[NPT]) {
+    const bool pin = id >= 0 && id < a.D;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      uint4 v = rg[k];
+      if (PRO) v = affine_relu8(v, scv, shv);
+      const bool keep = pin && ok[k];
+      v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+      *reinterpret_cast<uint4*>(smem + slot * PLB + (tid + k * 256) * 16) = v;
+    }
+  };
+  auto load_y = [&](int od, uint4 (&rg)[2]) {
+    const int odc = min(od, a.D - 1);
+    const bf16* yp = a.dy + ((size_t)n * a.D + odc) * plane * 16;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) rg[k] = *reinterpret_cast<const uint4*>(yp + yoff[k]);
+  };
+  auto store_y = [&](int od, int buf, uint4 (&rg)[2]) {
+    const bool pin = od < d1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      uint4 v = rg[k];
+      const bool keep = pin && yok[k];
+      v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+      bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+      bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
+      *reinterpret_cast<uint4*>(ys + buf * YPL + (tid + k * 256) * 16) = v;
+    }
+  };
+
+  // ---- fill: x planes d0-1, d0, d0+1 and dy plane d0
+  {
+    uint4 r0[NPT], r1[NPT], r2[NPT], y0[2];
+    load_x(d0 - 1, r0);
+    load_x(d0, r1);
+    load_x(d0 + 1, r2);
+    load_y(d0, y0);
+    store_x(d0 - 1, 0, r0);
+    store_x(d0, 1, r1);
+    store_x(d0 + 1, 2, r2);
+    store_y(d0, 0, y0);
+  }
+  __syncthreads();
+
+  f32x4 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // lane part of the operand addresses: voxel column wv = 4g + q, 8 bytes (4 channels) at p
+  const int wv = 4 * g + q;
+  const int xlane = wv * 32 + p * 8;
+  const int ylane = wv * 32 + p * 8;
+  // this wave's taps: t = wave + 4*tt; in-plane byte offset and kd of each (phantom tap 27 for wave 3 reads tap 26)
+  int toff[7], tkd[7];
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt) {
+    int t = wave + 4 * tt;
+    if (t > 26) t = 26;
+    tkd[tt] = t / 9;
+    toff[tt] = (((t / 3) % 3) * HW + t % 3) * 32;
+  }
+  const bool last_real = wave + 24 < 27;           // tt = 6 is a real tap for waves 0..2 only
+
+  const int np = d1 - d0;
+  for (int it = 0; it < np; ++it) {
+    const int od = d0 + it;
+    uint4 prex[NPT], prey[2];
+    load_x(od + 2, prex);
+    load_y(od + 1, prey);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const char* yb = ys + (it & 1) * YPL + ylane;
+    int xb[7];
+#pragma unroll
+    for (int tt = 0; tt < 7; ++tt) xb[tt] = ((it + tkd[tt]) & (R - 1)) * PLB + toff[tt] + xlane;
+
+    // K step s = (row pair rp, half h): voxels (2rp, 16h + wv) and (2rp + 1, 16h + wv)
+    auto read_step = [&](int s, bf16x8& af, bf16x8 (&bf)[7]) {
+      const int rp = s >> 1, h = s & 1;
+      const int yo = ((2 * rp) * TW + 16 * h) * 32;
+      af = tr_pair_m(yb + yo, yb + yo + TW * 32);
+      const int xo = ((2 * rp) * HW + 16 * h) * 32;
+#pragma unroll
+      for (int tt = 0; tt < 7; ++tt) bf[tt] = tr_pair_m(smem + xb[tt] + xo, smem + xb[tt] + xo + HW * 32);
+    };
+    bf16x8 afA, afB, bA[7], bB[7];
+    read_step(0, afA, bA);
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) {
+      read_step(s + 1, afB, bB);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tt = 0; tt < 7; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afA, bA[tt], acc[tt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < 8) read_step(s + 2, afA, bA);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tt = 0; tt < 7; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afB, bB[tt], acc[tt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    store_x(od + 2, (it + 3) & (R - 1), prex);
+    store_y(od + 1, (it + 1) & 1, prey);
+    __syncthreads();
+  }
+
+  // ---- partial results: D layout col = ci = lane&15, rows co = (lane>>4)*4 + j
+  float* part = a.part + (size_t)blockIdx.x * 27 * 256;
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt) {
+    const int t = wave + 4 * tt;
+    if (tt < 6 || last_real) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[(t * 16 + g * 4 + j) * 16 + (lane & 15)] = acc[tt][j];
+    }
+  }
+  if (a.bpart) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);       // [256][8]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 16) {
+      const int pc = tid / 8, j = tid % 8;
+      float s = 0.f;
+      for (int k = pc; k < 256; k += 2) s += red[k * 8 + j];
+      a.bpart[(size_t)blockIdx.x * 16 + tid] = s;
+    }
+  }
+}
+
+static int march_dl(int64_t cols, int D) {
+  static int dl_env = -1;
+  if (dl_env < 0) { const char* e = getenv("DEVIS_MARCH_DL"); dl_env = e ? atoi(e) : 0; }
+  if (dl_env > 0) return dl_env;
+  int dl = 32;
+  while (dl > 8 && cols * cdiv(D, dl) < 512) dl >>= 1;
+  return dl;
+}
+
+// stride-1 3x3x3, Cout = 16, Cin = 16 (or 4), bf16.  query: only report the workspace size.
+int wgrad3_c16_march(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,
+                     float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t s, bool query, size_t* need) {
+  if (d->dtype != DEVIS_BF16 || d->Cout != 16 || (d->C1 != 16 && d->C1 != 4) || d->C2 != 0 || d->SD != 1) return DEVIS_ERR_UNSUPPORTED;
+  if (d->OD != d->ID || d->OH != d->IH || d->OW != d->IW) return DEVIS_ERR_UNSUPPORTED;
+  if (d->IH * d->IW * 16 >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
+  if (d->C1 == 4 && sc) return DEVIS_ERR_UNSUPPORTED;
+  WgMarchArgs a;
+  a.N = (int)d->N; a.D = (int)d->OD; a.H = (int)d->OH; a.W = (int)d->OW;
+  a.nth = (int)cdiv(a.H, 8); a.ntw = (int)cdiv(a.W, 32);
+  a.DL = march_dl((int64_t)a.N * a.nth * a.ntw, a.D);
+  a.ndc = (int)cdiv(a.D, a.DL);
+  const int64_t blocks = (int64_t)a.N * a.ndc * a.nth * a.ntw;
+  if (blocks > 65535) return DEVIS_ERR_UNSUPPORTED;
+  const size_t part_bytes = (size_t)blocks * 27 * 256 * sizeof(float);
+  const size_t total = part_bytes + (size_t)blocks * 16 * sizeof(float);
+  if (query) { *need = total; return DEVIS_OK; }
+  if (!ws || ws_bytes < total) return DEVIS_ERR_WORKSPACE;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.sc = sc; a.sh = sh;
+  a.part = (float*)ws; a.bpart = dbias ? (float*)((char*)ws + part_bytes) : nullptr;
+  constexpr int LDS = 4 * 3 * 256 * 16 + 2 * 8 * 32 * 32;
+  const dim3 grid((unsigned)blocks);
+  if (d->C1 == 4) hipLaunchKernelGGL((k_wgrad3_c16_march<false, true>), grid, dim3(256), LDS, s, a);
+  else if (sc) hipLaunchKernelGGL((k_wgrad3_c16_march<true, false>), grid, dim3(256), LDS, s, a);
+  else hipLaunchKernelGGL((k_wgrad3_c16_march<false, false>), grid, dim3(256), LDS, s, a);
+  int rc = launch_status();
+  if (rc) return rc;
+  return launch_wgrad_reduce(a.part, a.bpart, (int)blocks, 16, 16, (int)d->C1, dw, dbias, s);
+}
+
+}  // namespace devis

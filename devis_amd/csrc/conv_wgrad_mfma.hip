@@ -12,6 +12,8 @@
 #include "common.h"
 #include "mfma_common.h"
 
+#include <stdlib.h>
+
 namespace devis {
 
 struct WgArgs {
@@ -233,6 +235,17 @@ k_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ bpart, 
   }
 }
 
+int launch_wgrad_reduce(const float* part, const float* bpart, int gx, int Cout, int Cin, int cin_real, float* dw,
+                        float* dbias, hipStream_t s) {
+  const int64_t n_out = (int64_t)Cout * Cin * 27 + (dbias ? Cout : 0);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv(n_out * 8, 256)), dim3(256), 0, s, part, bpart, gx, Cout, Cin,
+                     cin_real, dw, dbias);
+  return launch_status();
+}
+
+int wgrad3_c16_march(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,
+                     float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t s, bool query, size_t* need);
+
 static int wg_gx(int64_t ntiles, int nslab) {
   int64_t cap = 512 / nslab;
   if (cap < 8) cap = 8;
@@ -279,6 +292,17 @@ static int wgrad_dispatch(const devis_conv_desc* d, const void* x, const float* 
   const int ci = (int)d->C1, co = (int)d->Cout, st = d->SD;
 #define WG(CIS, COS, TD, TH, S, SM) return launch_wgrad<CIS, COS, TD, TH, S, SM>(d, x, sc, sh, dy, dw, dbias, ws, ws_bytes, s, query, need)
   if (st == 1) {
+    static const bool no_march = getenv("DEVIS_NO_MARCH") != nullptr;
+    if (!no_march && co == 16 && (ci == 16 || (ci == 4 && !sc))) {
+      const int rc = wgrad3_c16_march(d, x, sc, sh, dy, dw, dbias, ws, ws_bytes, s, query, need);
+      if (rc != DEVIS_ERR_UNSUPPORTED && !(query && ci == 4)) return rc;
+      if (query && ci == 4) {       // the prologue variant of the 4-channel layer runs on the tile kernel: size for both
+        size_t other = 0;
+        const int rc2 = launch_wgrad<16, 16, 4, 4, 1, true>(d, x, sc, sh, dy, dw, dbias, ws, ws_bytes, s, true, &other);
+        if (rc2 == DEVIS_OK && other > *need) *need = other;
+        return rc == DEVIS_OK ? rc : rc2;
+      }
+    }
     if (ci == 4 && co == 16) WG(16, 16, 4, 4, 1, true);
     if (ci == 16 && co == 16) WG(16, 16, 4, 4, 1, false);
     if (ci % 32 == 0 && co % 32 == 0 && ci <= 128 && co <= 128) WG(32, 32, 4, 4, 1, false);
