@@ -11,6 +11,7 @@
 // (deterministic, no atomics) and writes the PyTorch [Cout][Cin][27] fp32 layout plus dbias.
 #include "common.h"
 #include "mfma_common.h"
+#include "wgrad_reduce.h"
 
 #include <stdlib.h>
 
@@ -206,41 +207,15 @@ k_wgrad3_mfma(WgArgs a) {
   }
 }
 
-// dw[co][ci<cin_real][t] = sum_gx part[gx][t][co][ci];  dbias[co] = sum_gx bpart[gx][co]
-// 8 lanes share one output (gx = sub, sub+8, ...) and combine with a fixed xor tree: deterministic.
-__global__ void __launch_bounds__(256)
-k_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ bpart, int gx, int Cout, int Cin, int cin_real,
-               float* __restrict__ dw, float* __restrict__ dbias) {
-  const int64_t total = (int64_t)27 * Cout * Cin;
-  const int64_t o = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-  const int sub = threadIdx.x & 7;
-  const bool is_w = o < total;
-  const bool is_b = !is_w && dbias && (o - total) < Cout;
-  float s = 0.f;
-  if (is_w) {
-    for (int k = sub; k < gx; k += 8) s += part[(int64_t)k * total + o];
-  } else if (is_b) {
-    for (int k = sub; k < gx; k += 8) s += bpart[(int64_t)k * Cout + (o - total)];
-  }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  if (sub == 0) {
-    if (is_w) {
-      const int ci = (int)(o % Cin), co = (int)((o / Cin) % Cout), t = (int)(o / ((int64_t)Cin * Cout));
-      if (ci < cin_real) dw[((int64_t)co * cin_real + ci) * 27 + t] = s;
-    } else if (is_b) {
-      dbias[o - total] = s;
-    }
-  }
-}
-
+// dw[co][ci<cin_real][t] = sum_gx part[gx][t][co][ci];  dbias[co] = sum_gx bpart[gx][co]   (wgrad_reduce.h)
 int launch_wgrad_reduce(const float* part, const float* bpart, int gx, int Cout, int Cin, int cin_real, float* dw,
                         float* dbias, hipStream_t s) {
-  const int64_t n_out = (int64_t)Cout * Cin * 27 + (dbias ? Cout : 0);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv(n_out * 8, 256)), dim3(256), 0, s, part, bpart, gx, Cout, Cin,
-                     cin_real, dw, dbias);
-  return launch_status();
+  RedArgs r;
+  r.part = part; r.bpart = bpart; r.dw = dw; r.dbias = dbias;
+  r.nparts = gx; r.nbparts = gx; r.Cb = Cout;
+  r.pstride = (int64_t)27 * Cout * Cin; r.total = r.pstride;
+  r.mode = RED_CONV3; r.A = Cout; r.B = Cin; r.cin_real = cin_real;
+  return launch_reduce_partials(r, s);
 }
 
 int wgrad3_c16_march(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,
@@ -277,10 +252,7 @@ static int launch_wgrad(const devis_conv_desc* d, const void* x, const float* sc
   else hipLaunchKernelGGL((k_wgrad3_mfma<CIS, COS, TD, TH, S, false, SMALLC>), grid, dim3(256), C::LDS_BYTES, s, a);
   int rc = launch_status();
   if (rc) return rc;
-  const int64_t n_out = (int64_t)Cout * Cin * 27 + (dbias ? Cout : 0);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv(n_out * 8, 256)), dim3(256), 0, s,
-                     a.part, a.bpart, gx, Cout, Cin, cin_real, dw, dbias);
-  return launch_status();
+  return launch_wgrad_reduce(a.part, a.bpart, gx, Cout, Cin, cin_real, dw, dbias, s);
 }
 
 static int wgrad_dispatch(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,

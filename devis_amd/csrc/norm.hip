@@ -136,18 +136,17 @@ k_moments(const T* __restrict__ x, const T* __restrict__ dy, const float* __rest
 
 // out[n][c][j] = sum_chunk partial[n][chunk][c][j]
 __global__ void k_moments_final(const double* __restrict__ partial, int64_t chunks, int64_t C, int64_t total, double* __restrict__ out) {
-  // 8 lanes per output (chunk = sub, sub+8, ...), combined with a fixed xor tree: deterministic
-  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;   // over N*C*2
-  const int sub = threadIdx.x & 7;
+  // 32 lanes per output (chunk = sub, sub+32, ...), combined with a fixed xor tree: deterministic
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;   // over N*C*2
+  const int sub = threadIdx.x & 31;
   double a = 0.0;
   if (i < total) {
     const int64_t n = i / (C * 2), rem = i % (C * 2);
     const double* p = partial + n * chunks * C * 2 + rem;
-    for (int64_t k = sub; k < chunks; k += 8) a += p[k * C * 2];
+    for (int64_t k = sub; k < chunks; k += 32) a += p[k * C * 2];
   }
-  a += __shfl_xor(a, 1, 64);
-  a += __shfl_xor(a, 2, 64);
-  a += __shfl_xor(a, 4, 64);
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) a += __shfl_xor(a, o, 64);
   if (i < total && sub == 0) out[i] = a;
 }
 
@@ -381,7 +380,11 @@ static int moments_impl(int mode, const void* x, const void* dy, const float* sc
   if (!vec_ok(C, dtype)) return DEVIS_ERR_UNSUPPORTED;
   if (ws_bytes < devis_moments_workspace_bytes(N, V, C)) return DEVIS_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t rows = mom_rows(C, dtype == DEVIS_F32 ? 4 : 8);
+  // rows per block: at least 16 per thread, more on large tensors so that about 512 blocks cover the tensor
+  // (each block then leaves one partial; the second stage stays a few microseconds)
+  int64_t rows = mom_rows(C, dtype == DEVIS_F32 ? 4 : 8);
+  const int64_t mult = (N * V) / (rows * 512);
+  if (mult > 1) rows *= mult;
   const int64_t chunks = cdiv(V, rows);
   if (chunks > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)chunks, (unsigned)N);
@@ -392,7 +395,7 @@ static int moments_impl(int mode, const void* x, const void* dy, const float* sc
   int rc = launch_status();
   if (rc) return rc;
   const int64_t total = N * C * 2;
-  hipLaunchKernelGGL(k_moments_final, dim3((unsigned)cdiv(total * 8, 256)), dim3(256), 0, s, (const double*)ws, chunks, C, total, out);
+  hipLaunchKernelGGL(k_moments_final, dim3((unsigned)cdiv(total * 32, 256)), dim3(256), 0, s, (const double*)ws, chunks, C, total, out);
   return launch_status();
 }
 

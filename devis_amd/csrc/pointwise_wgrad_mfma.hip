@@ -3,11 +3,13 @@
 //   ConvTranspose k == stride:  dW[ci][co][p] = sum_i x[i][ci]  * dy[2i+p][co]      (one grid.y slice per tap p)
 // K = voxels.  Every wave takes its own 32-voxel K steps: it copies the two [voxel][channel] slabs into a
 // private LDS image ([16-channel tile][32 voxels][32 B], conflict-free for the transposing reads), reads
-// them back with ds_read_b64_tr_b16 and accumulates all (M tile, N tile) pairs in registers.  Per-wave
-// partials go to the workspace; a second kernel adds them in a fixed order (deterministic) and writes the
-// PyTorch fp32 layouts plus dbias.
+// them back with ds_read_b64_tr_b16 and accumulates all (M tile, N tile) pairs in registers; the next
+// step's global loads are in flight meanwhile.  The four waves' sums are combined in LDS, one partial per
+// block goes to the workspace and k_reduce_partials (wgrad_reduce.h) adds the partials in a fixed order
+// (deterministic) and writes the PyTorch fp32 layouts plus dbias.
 #include "common.h"
 #include "mfma_common.h"
+#include "wgrad_reduce.h"
 
 namespace devis {
 
@@ -62,22 +64,23 @@ k_pw_wgrad(PwWgArgs a) {
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
 
   constexpr int MPPV = MTO * 2, NPPV = MTI * 2;       // 16-byte pieces per voxel in the (padded) images
-  for (int it = 0; it < a.iters; ++it) {
+  // A wave's 32-voxel step is MTO + MTI pieces per lane.  The pieces of step it+1 are fetched into
+  // registers before the MFMAs of step it run, so HBM latency hides behind the LDS/MFMA phase.
+  uint4 mr[MTO], nr[MTI];
+  auto fetch = [&](int it) {
     const int64_t seg = ((int64_t)blockIdx.x * a.iters + it) * 4 + wave;
     const int64_t v0 = seg * 32;
-    __syncthreads();
-    for (int i = lane; i < 32 * MPPV; i += 64) {
+#pragma unroll
+    for (int k = 0; k < MTO; ++k) {
+      const int i = lane + 64 * k;
       const int v = i / MPPV, pc = i % MPPV;
       const int64_t gv = v0 + v;
-      uint4 val = make_uint4(0u, 0u, 0u, 0u);
-      if (gv < a.NV) val = load_piece(a.msrc + gv * a.M, pc * 8, a.M);
-      if (a.bias_side == 1) {
-        bsum[0] += bf_lo(val.x); bsum[1] += bf_hi(val.x); bsum[2] += bf_lo(val.y); bsum[3] += bf_hi(val.y);
-        bsum[4] += bf_lo(val.z); bsum[5] += bf_hi(val.z); bsum[6] += bf_lo(val.w); bsum[7] += bf_hi(val.w);
-      }
-      *reinterpret_cast<uint4*>(mimg + ((pc >> 1) * 32 + v) * 32 + (pc & 1) * 16) = val;
+      mr[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (gv < a.NV) mr[k] = load_piece(a.msrc + gv * a.M, pc * 8, a.M);
     }
-    for (int i = lane; i < 32 * NPPV; i += 64) {
+#pragma unroll
+    for (int k = 0; k < MTI; ++k) {
+      const int i = lane + 64 * k;
       const int v = i / NPPV, pc = i % NPPV;
       const int64_t gv = v0 + v;
       uint4 val = make_uint4(0u, 0u, 0u, 0u);
@@ -96,6 +99,28 @@ k_pw_wgrad(PwWgArgs a) {
           val = load_piece(a.n1 + ov * a.N, c, a.N);
         }
       }
+      nr[k] = val;
+    }
+  };
+  fetch(0);
+  for (int it = 0; it < a.iters; ++it) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MTO; ++k) {
+      const int i = lane + 64 * k;
+      const int v = i / MPPV, pc = i % MPPV;
+      const uint4 val = mr[k];
+      if (a.bias_side == 1) {
+        bsum[0] += bf_lo(val.x); bsum[1] += bf_hi(val.x); bsum[2] += bf_lo(val.y); bsum[3] += bf_hi(val.y);
+        bsum[4] += bf_lo(val.z); bsum[5] += bf_hi(val.z); bsum[6] += bf_lo(val.w); bsum[7] += bf_hi(val.w);
+      }
+      *reinterpret_cast<uint4*>(mimg + ((pc >> 1) * 32 + v) * 32 + (pc & 1) * 16) = val;
+    }
+#pragma unroll
+    for (int k = 0; k < MTI; ++k) {
+      const int i = lane + 64 * k;
+      const int v = i / NPPV, pc = i % NPPV;
+      const uint4 val = nr[k];
       if (a.bias_side == 2) {
         bsum[0] += bf_lo(val.x); bsum[1] += bf_hi(val.x); bsum[2] += bf_lo(val.y); bsum[3] += bf_hi(val.y);
         bsum[4] += bf_lo(val.z); bsum[5] += bf_hi(val.z); bsum[6] += bf_lo(val.w); bsum[7] += bf_hi(val.w);
@@ -103,6 +128,7 @@ k_pw_wgrad(PwWgArgs a) {
       *reinterpret_cast<uint4*>(nimg + ((pc >> 1) * 32 + v) * 32 + (pc & 1) * 16) = val;
     }
     __syncthreads();
+    if (it + 1 < a.iters) fetch(it + 1);
     const int vq = 4 * g + q;       // this lane addresses voxel rows vq and 16+vq of the 32-voxel step
     bf16x8 af[MTO];
 #pragma unroll
@@ -117,63 +143,64 @@ k_pw_wgrad(PwWgArgs a) {
     }
   }
 
-  const int T = gridDim.y;
-  const int64_t pidx = (int64_t)blockIdx.x * 4 + wave;
-  float* part = a.part + (pidx * T + tap) * a.M * a.N;
+  // ---- the four waves' accumulators are added in wave order through LDS: one partial per block
+  float* red = reinterpret_cast<float*>(smem);          // MTO*MTI KB <= 4*(MTO+MTI) KB
+  for (int w = 1; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
 #pragma unroll
-  for (int mo = 0; mo < MTO; ++mo)
+      for (int mo = 0; mo < MTO; ++mo)
 #pragma unroll
-    for (int mi = 0; mi < MTI; ++mi) {
-      const int n = mi * 16 + (lane & 15);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = mo * 16 + g * 4 + j;
-        if (m < a.M && n < a.N) part[(int64_t)m * a.N + n] = acc[mo][mi][j];
-      }
+        for (int mi = 0; mi < MTI; ++mi)
+          *reinterpret_cast<f32x4*>(red + ((mo * MTI + mi) * 64 + lane) * 4) = acc[mo][mi];
     }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int mo = 0; mo < MTO; ++mo)
+#pragma unroll
+        for (int mi = 0; mi < MTI; ++mi) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((mo * MTI + mi) * 64 + lane) * 4);
+          acc[mo][mi][0] += v[0]; acc[mo][mi][1] += v[1]; acc[mo][mi][2] += v[2]; acc[mo][mi][3] += v[3];
+        }
+    }
+  }
+  const int T = gridDim.y;
+  const int64_t pidx = blockIdx.x;
+  if (wave == 0) {
+    float* part = a.part + (pidx * T + tap) * a.M * a.N;
+#pragma unroll
+    for (int mo = 0; mo < MTO; ++mo)
+#pragma unroll
+      for (int mi = 0; mi < MTI; ++mi) {
+        const int n = mi * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = mo * 16 + g * 4 + j;
+          if (m < a.M && n < a.N) part[(int64_t)m * a.N + n] = acc[mo][mi][j];
+        }
+      }
+  }
   if (a.bpart) {
-    // lanes with equal (lane % PPV) hold the same 8 channels: combine them through LDS (fixed order)
+    // lanes with equal (lane % PPV) hold the same 8 channels: combine them through LDS (fixed order),
+    // then the four waves in wave order
     const int PPV = a.bias_side == 1 ? MPPV : NPPV;
     const int Cb = a.bias_side == 1 ? a.M : a.N;
     __syncthreads();
-    float* red = reinterpret_cast<float*>(mimg);      // [64][8] floats = 2 KB <= the wave's own region
+    float* wred = reinterpret_cast<float*>(mimg);     // [64][8] floats = 2 KB <= the wave's own region
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[lane * 8 + j] = bsum[j];
+    for (int j = 0; j < 8; ++j) wred[lane * 8 + j] = bsum[j];
     __syncthreads();
+    float s = 0.f;
     if (lane < PPV * 8) {
       const int pc = lane / 8, j = lane % 8;
-      float s = 0.f;
-      for (int k = pc; k < 64; k += PPV) s += red[k * 8 + j];
-      if (lane < Cb) a.bpart[(pidx * T + tap) * Cb + lane] = s;
+      for (int k = pc; k < 64; k += PPV) s += wred[k * 8 + j];
     }
-  }
-}
-
-// out[(m*N + n)*T + p] = sum_k part[((k*T + p)*M + m)*N + n];  dbias[c] = sum_{k,p} bpart[(k*T + p)*Cb + c]
-// 8 lanes share one output (k = sub, sub+8, ...), combined with a fixed xor tree: deterministic.
-__global__ void __launch_bounds__(256)
-k_pw_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ bpart, int nparts, int T, int M, int N,
-                  int Cb, float* __restrict__ dw, float* __restrict__ dbias) {
-  const int64_t total = (int64_t)M * N * T;
-  const int64_t o = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-  const int sub = threadIdx.x & 7;
-  float s = 0.f;
-  const bool is_w = o < total;
-  const bool is_b = !is_w && dbias && (o - total) < Cb;
-  if (is_w) {
-    const int p = (int)(o % T);
-    const int64_t mn = o / T;
-    for (int k = sub; k < nparts; k += 8) s += part[((int64_t)k * T + p) * M * N + mn];
-  } else if (is_b) {
-    const int c = (int)(o - total);
-    for (int k = sub; k < nparts * T; k += 8) s += bpart[(int64_t)k * Cb + c];
-  }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  if (sub == 0) {
-    if (is_w) dw[o] = s;
-    else if (is_b) dbias[o - total] = s;
+    __syncthreads();
+    red[wave * 64 + lane] = s;
+    __syncthreads();
+    if (wave == 0 && lane < PPV * 8 && lane < Cb)
+      a.bpart[(pidx * T + tap) * Cb + lane] = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
   }
 }
 
@@ -182,12 +209,17 @@ struct PwWgPlan { int gx, iters, nparts, T; size_t part_bytes, total_bytes; };
 static PwWgPlan pw_plan(int64_t NV, int T, int M, int N, int Cb) {
   PwWgPlan p;
   const int64_t segs = cdiv(NV, 32);
+  // every block leaves one fp32 partial [T-slice][M][N]: enough blocks to keep several waves per SIMD in
+  // flight on the big layers (their partials are tiny), but at most ~16 MB of partials in total
   int64_t gx = cdiv(segs, 4);
-  const int64_t cap = T >= 8 ? 64 : (T >= 4 ? 128 : 256);
+  int64_t cap = 1024 / T;
+  const int64_t by_bytes = ((int64_t)16 << 20) / ((int64_t)T * M * N * (int64_t)sizeof(float));
+  if (by_bytes < cap) cap = by_bytes;
+  if (cap < 16) cap = 16;
   if (gx > cap) gx = cap;
   p.gx = (int)gx;
   p.iters = (int)cdiv(segs, gx * 4);
-  p.nparts = p.gx * 4;
+  p.nparts = p.gx;
   p.T = T;
   p.part_bytes = (size_t)p.nparts * T * M * N * sizeof(float);
   p.total_bytes = p.part_bytes + (size_t)p.nparts * T * Cb * sizeof(float);
@@ -212,10 +244,13 @@ static int pw_wgrad_launch(PwWgArgs& a, const PwWgPlan& pl, int Cb, float* dw, f
 #undef PWG
   int rc = launch_status();
   if (rc) return rc;
-  const int64_t outs = (int64_t)a.M * a.N * pl.T + (dbias ? Cb : 0);
-  hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3((unsigned)cdiv(outs * 8, 256)), dim3(256), 0, s, a.part, a.bpart, pl.nparts,
-                     pl.T, a.M, a.N, Cb, dw, dbias);
-  return launch_status();
+  // out[(m*N + n)*T + p] = sum_k part[((k*T + p)*M + m)*N + n];  dbias[c] = sum_{k,p} bpart[(k*T + p)*Cb + c]
+  RedArgs r;
+  r.part = a.part; r.bpart = a.bpart; r.dw = dw; r.dbias = dbias;
+  r.nparts = pl.nparts; r.nbparts = pl.nparts * pl.T; r.Cb = Cb;
+  r.pstride = (int64_t)pl.T * a.M * a.N; r.total = r.pstride;
+  r.mode = RED_PW; r.A = pl.T; r.B = a.M * a.N; r.cin_real = 0;
+  return launch_reduce_partials(r, s);
 }
 
 static bool pw_tiles_ok(int M, int N) {

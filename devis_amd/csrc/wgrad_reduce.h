@@ -1,0 +1,97 @@
+// Second stage of the deterministic weight-gradient reductions: sums the per-block fp32 partials the
+// wgrad kernels leave in the workspace and scatters the result into the PyTorch weight layout.
+// A block is 64 float4 columns x KG partial groups: lanes run along the partial (coalesced 1 KB reads),
+// wave g adds partials g, g+KG, ... (4 independent loads in flight), the KG waves combine through LDS
+// in a fixed order.  No atomics: the same inputs always give the same bits.
+#pragma once
+#include "common.h"
+
+namespace devis {
+
+enum { RED_CONV3 = 0, RED_PW = 1 };
+
+struct RedArgs {
+  const float* part;    // [nparts][pstride]
+  const float* bpart;   // [nbparts][Cb] or null
+  float* dw;
+  float* dbias;         // null: no bias
+  int nparts, nbparts, Cb;
+  int64_t pstride;      // floats between partials
+  int64_t total;        // floats of a partial that are summed (multiple of 4)
+  int mode;             // RED_CONV3: o = (t*A + co)*B + ci -> dw[(co*cin_real + ci)*27 + t], ci < cin_real
+  int A, B, cin_real;   // RED_PW:    o = p*B + mn          -> dw[mn*A + p]   (A = taps T, B = M*N)
+};
+
+#define RED_KG 16
+
+template <int MODE>
+__global__ void __launch_bounds__(64 * RED_KG)
+k_reduce_partials(RedArgs a) {
+  __shared__ float4 red[RED_KG][64];
+  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int64_t n4 = a.total / 4;
+  const int64_t o4 = (int64_t)blockIdx.x * 64 + lane;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (o4 < n4) {
+    const float* p = a.part + o4 * 4;
+    int k = kg;
+    for (; k + 3 * RED_KG < a.nparts; k += 4 * RED_KG) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)k * a.pstride);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(k + RED_KG) * a.pstride);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(k + 2 * RED_KG) * a.pstride);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(k + 3 * RED_KG) * a.pstride);
+      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; k < a.nparts; k += RED_KG) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)k * a.pstride);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  } else if (a.dbias) {
+    const int64_t c0 = (o4 - n4) * 4;
+    float* sv = reinterpret_cast<float*>(&s);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < a.Cb)
+        for (int k = kg; k < a.nbparts; k += RED_KG) sv[j] += a.bpart[(int64_t)k * a.Cb + c0 + j];
+  }
+  red[kg][lane] = s;
+  __syncthreads();
+  if (kg != 0) return;
+#pragma unroll
+  for (int j = 1; j < RED_KG; ++j) {
+    const float4 v = red[j][lane];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float* sv = reinterpret_cast<const float*>(&s);
+  if (o4 < n4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t o = o4 * 4 + j;
+      if (MODE == RED_CONV3) {
+        const int ci = (int)(o % a.B), co = (int)((o / a.B) % a.A), t = (int)(o / ((int64_t)a.A * a.B));
+        if (ci < a.cin_real) a.dw[((int64_t)co * a.cin_real + ci) * 27 + t] = sv[j];
+      } else {
+        const int64_t mn = o % a.B;
+        const int p = (int)(o / a.B);
+        a.dw[mn * a.A + p] = sv[j];
+      }
+    }
+  } else if (a.dbias) {
+    const int64_t c0 = (o4 - n4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < a.Cb) a.dbias[c0 + j] = sv[j];
+  }
+}
+
+static inline int launch_reduce_partials(const RedArgs& a, hipStream_t s) {
+  const int64_t n4 = a.total / 4 + (a.dbias ? (a.Cb + 3) / 4 : 0);
+  if (a.mode == RED_CONV3) hipLaunchKernelGGL(k_reduce_partials<RED_CONV3>, dim3((unsigned)cdiv(n4, 64)), dim3(64 * RED_KG), 0, s, a);
+  else hipLaunchKernelGGL(k_reduce_partials<RED_PW>, dim3((unsigned)cdiv(n4, 64)), dim3(64 * RED_KG), 0, s, a);
+  return launch_status();
+}
+
+}  // namespace devis
