@@ -249,6 +249,9 @@ static int launch_conv3(const devis_conv_desc* d, const void* x, const void* w, 
 int conv3_c16_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
                     const float* sh, const void* res, void* y, hipStream_t s);
 
+int conv3_deep(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
+               const float* sh, const void* res, void* y, hipStream_t s);
+
 static bool is_3x3x3(const devis_conv_desc* d) {
   return d->KD == 3 && d->KH == 3 && d->KW == 3 && d->PD == 1 && d->PH == 1 && d->PW == 1 && d->SD == d->SH && d->SH == d->SW;
 }
@@ -265,6 +268,8 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
   if (st == 1) {
     static const bool no_march = getenv("DEVIS_NO_MARCH") != nullptr;
     if (!no_march && co == 16 && (ci == 16 || (ci == 4 && !sc))) return conv3_c16_march(d, x1, w, bias, sc, sh, res, y, s);
+    static const bool no_deep = getenv("DEVIS_NO_DEEP") != nullptr;
+    if (!no_deep && ci == co && (ci == 64 || ci == 128)) return conv3_deep(d, x1, w, bias, sc, sh, res, y, s);
     if (ci == 16 && co == 16) return launch_conv3<16, 16, 8, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
     if (ci == 4 && co == 16 && !sc) return launch_conv3<16, 16, 8, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
     if (ci == 32 && co == 32) return launch_conv3<32, 32, 4, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
