@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
 
 
@@ -156,6 +156,8 @@ def main():
         opt.step()
         return loss
 
+    from devis_amd.train import freeze_gc
+    freeze_gc()                                # as devis_amd.train.train() does before its loop
     for _ in range(a.warmup):
         loss = step()
     if dist is not None:

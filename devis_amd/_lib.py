@@ -46,6 +46,8 @@ class EvidParams(C.Structure):
 
 
 CRIT_DCE, CRIT_DCEU, CRIT_CE, CRIT_MSE, CRIT_KL = range(5)
+PACK_CONV, PACK_CONV_DGRAD, PACK_CONVT, PACK_CONVT_DGRAD = range(4)
+PACK_CHUNK = 1024
 
 _P, _I64, _I, _F, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _CD, _CTD, _EP = C.POINTER(ConvDesc), C.POINTER(ConvTDesc), C.POINTER(EvidParams)
@@ -59,6 +61,7 @@ SIGNATURES = {
     "devis_nxc_to_ncx": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
     "devis_pack_conv_weight": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
     "devis_pack_convT_weight": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
+    "devis_pack_weights_batch": (_I, [_P, _P, _I64, _I, _P]),
     "devis_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devis_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P]),
     "devis_repack_conv_weight_dgrad": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),

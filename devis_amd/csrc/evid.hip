@@ -8,7 +8,7 @@
 namespace devis {
 
 #define EV_MAXK DEVIS_EVID_MAX_K
-#define EV_BLOCKS 2048
+#define EV_BLOCKS 1024
 #define EV_NACC (1 + 3 * EV_MAXK)
 
 __device__ __forceinline__ float softplus_f(float z) { return z > 20.f ? z : log1pf(expf(z)); }
@@ -19,30 +19,70 @@ __device__ __forceinline__ float dsoftplus_f(float z) {
   return t / (t + 1.f);
 }
 
-// psi(x), x >= 1: recurrence up to x >= 6, then the asymptotic series (error < 2e-10 at x = 6)
+// Training-path variants on the hardware exp/log/rcp (1 ulp): |error| < 1e-7 + 1e-6 * value, far inside the
+// parity bars; the inference head keeps the libm forms above (its argmax / threshold masks are bit-exact).
+__device__ __forceinline__ float softplus_fast(float z) {
+  const float t = __expf(fminf(z, 20.f));
+  const float small = t * (1.f - t * (0.5f - t * 0.33333333f));      // log1p(t), t < 0.01
+  const float big = __logf(1.f + t);
+  return z > 20.f ? z : (t < 0.01f ? small : big);
+}
+__device__ __forceinline__ float dsoftplus_fast(float z) {
+  const float t = __expf(fminf(z, 20.f));
+  return z > 20.f ? 1.f : t * __builtin_amdgcn_rcpf(t + 1.f);
+}
+
+// ---- special functions on x >= 1 (alpha = softplus + 1 and sums of alphas), branch-free:
+// arguments below 6 are shifted up by 6 with ONE reciprocal / ONE extra log,
+//   sum_{i<6} 1/(x+i) = P'(x)/P(x),  sum_{i<6} log(x+i) = log P(x),  P(x) = x(x+1)...(x+5),
+// then the asymptotic series at X >= 6 (truncation < 1e-9).  Hardware rcp/log (1 ulp) are used: their
+// error is below the fp32 rounding of the terms they feed.
+__device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float log_f(float x) { return __logf(x); }
+
+// psi(x) and ln Gamma(x) together (they share P, 1/X and log X)
+__device__ __forceinline__ void psi_lgamma_f(float x, float& psi, float& lg) {
+  const bool small = x < 6.f;
+  const float xs = small ? x : 1.f;
+  const float a0 = xs * (xs + 1.f), a1 = (xs + 2.f) * (xs + 3.f), a2 = (xs + 4.f) * (xs + 5.f);
+  const float b0 = 2.f * xs + 1.f, b1 = 2.f * xs + 5.f, b2 = 2.f * xs + 9.f;
+  const float P = a0 * a1 * a2;
+  const float num = fmaf(b0, a1 * a2, fmaf(b1, a0 * a2, b2 * a0 * a1));
+  const float X = small ? x + 6.f : x;
+  const float xi = rcp_f(X), x2 = xi * xi, lx = log_f(X);
+  const float pser = x2 * (8.3333333333e-2f - x2 * (8.3333333333e-3f - x2 * (3.9682539683e-3f - x2 * (4.1666666667e-3f - x2 * 7.5757575758e-3f))));
+  const float lser = xi * (8.3333333333e-2f - x2 * (2.7777777778e-3f - x2 * (7.9365079365e-4f - x2 * 5.9523809524e-4f)));
+  psi = (lx - 0.5f * xi - pser) - (small ? num * rcp_f(P) : 0.f);
+  lg = ((X - 0.5f) * lx - X + 0.91893853320467f + lser) - (small ? log_f(P) : 0.f);
+}
 __device__ __forceinline__ float digamma_f(float x) {
-  float r = 0.f;
-  while (x < 6.f) { r -= 1.f / x; x += 1.f; }
-  const float xi = 1.f / x, x2 = xi * xi;
-  const float ser = x2 * (8.3333333333e-2f - x2 * (8.3333333333e-3f - x2 * (3.9682539683e-3f - x2 * (4.1666666667e-3f - x2 * 7.5757575758e-3f))));
-  return r + (logf(x) - 0.5f * xi - ser);
+  const bool small = x < 6.f;
+  const float xs = small ? x : 1.f;
+  const float a0 = xs * (xs + 1.f), a1 = (xs + 2.f) * (xs + 3.f), a2 = (xs + 4.f) * (xs + 5.f);
+  const float b0 = 2.f * xs + 1.f, b1 = 2.f * xs + 5.f, b2 = 2.f * xs + 9.f;
+  const float num = fmaf(b0, a1 * a2, fmaf(b1, a0 * a2, b2 * a0 * a1));
+  const float X = small ? x + 6.f : x;
+  const float xi = rcp_f(X), x2 = xi * xi;
+  const float pser = x2 * (8.3333333333e-2f - x2 * (8.3333333333e-3f - x2 * (3.9682539683e-3f - x2 * (4.1666666667e-3f - x2 * 7.5757575758e-3f))));
+  return (log_f(X) - 0.5f * xi - pser) - (small ? num * rcp_f(a0 * a1 * a2) : 0.f);
+}
+__device__ __forceinline__ float lgamma_f(float x) {
+  float psi, lg;
+  psi_lgamma_f(x, psi, lg);
+  return lg;
 }
 // psi'(x), x >= 1
 __device__ __forceinline__ float trigamma_f(float x) {
+  const bool small = x < 6.f;
+  const float xs = small ? x : 1.f;
   float r = 0.f;
-  while (x < 6.f) { const float xi = 1.f / x; r = fmaf(xi, xi, r); x += 1.f; }
-  const float xi = 1.f / x, x2 = xi * xi;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const float t = rcp_f(xs + (float)i); r = fmaf(t, t, r); }
+  const float X = small ? x + 6.f : x;
+  const float xi = rcp_f(X), x2 = xi * xi;
   // 1/x + 1/(2x^2) + 1/(6x^3) - 1/(30x^5) + 1/(42x^7) - 1/(30x^9) + 5/(66 x^11)
   const float ser = xi * (1.f + xi * 0.5f + x2 * (1.6666666667e-1f - x2 * (3.3333333333e-2f - x2 * (2.3809523810e-2f - x2 * (3.3333333333e-2f - x2 * 7.5757575758e-2f)))));
-  return r + ser;
-}
-// ln Gamma(x), x >= 1: shift to x >= 7 with one log of the product, then Stirling
-__device__ __forceinline__ float lgamma_f(float x) {
-  float prod = 1.f;
-  while (x < 7.f) { prod *= x; x += 1.f; }
-  const float xi = 1.f / x, x2 = xi * xi;
-  const float ser = xi * (8.3333333333e-2f - x2 * (2.7777777778e-3f - x2 * (7.9365079365e-4f - x2 * 5.9523809524e-4f)));
-  return (x - 0.5f) * logf(x) - x + 0.91893853320467f + ser - logf(prod);
+  return ser + (small ? r : 0.f);
 }
 
 __device__ __forceinline__ int load_label(const void* labels, int ldt, int64_t i) {
@@ -54,6 +94,7 @@ __device__ __forceinline__ int load_label(const void* labels, int ldt, int64_t i
 struct EvidShape {
   int64_t sN, sV, sK, N, V;
   int K;
+  int vec;   // channels-last rows of exactly 4 contiguous, aligned elements: one vector access per voxel
 };
 
 // criterion selector (devis_evid_params.kind) and the per-call constants
@@ -64,24 +105,51 @@ struct EvidParams {
   float lambda, a_au, eps;
 };
 
-template <typename T>
+__device__ __forceinline__ void load4(const float* p, float* out) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16* p, float* out) {
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  out[0] = __uint_as_float(t.x << 16); out[1] = __uint_as_float(t.x & 0xffff0000u);
+  out[2] = __uint_as_float(t.y << 16); out[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(bf16* p, const float* v) {
+  union { bf16 h[4]; uint2 u; } r;
+  r.h[0] = (bf16)v[0]; r.h[1] = (bf16)v[1]; r.h[2] = (bf16)v[2]; r.h[3] = (bf16)v[3];
+  *reinterpret_cast<uint2*>(p) = r.u;
+}
+
+// KT: compile-time class count (4) or 0 for the run-time K <= EV_MAXK path
+template <typename T, int KT>
 __device__ __forceinline__ void load_logits(const T* z, const EvidShape& s, int64_t n, int64_t v, float* out) {
+  const int K = KT ? KT : s.K;
   const T* p = z + n * s.sN + v * s.sV;
+  if (KT == 4 && s.vec) {
+    load4(p, out);
 #pragma unroll
-  for (int k = 0; k < EV_MAXK; ++k) out[k] = k < s.K ? ld(p + k * s.sK) : 0.f;
+    for (int k = 4; k < EV_MAXK; ++k) out[k] = 0.f;
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < EV_MAXK; ++k) out[k] = k < K ? ld(p + k * s.sK) : 0.f;
 }
 
 // e, alpha of one voxel from the input row; ed = the tensor the dice term is taken on
-template <typename T>
+template <typename T, int KT>
 __device__ __forceinline__ void load_voxel(const T* in, const float* ev_in, const EvidShape& s, const EvidParams& p,
                                            int64_t n, int64_t v, float* zz, float* e, float* al, float* ed) {
-  load_logits<T>(in, s, n, v, zz);
+  const int K = KT ? KT : s.K;
+  load_logits<T, KT>(in, s, n, v, zz);
 #pragma unroll
   for (int k = 0; k < EV_MAXK; ++k) {
-    if (k < s.K) {
+    if (k < K) {
       if (p.raw) { al[k] = zz[k]; e[k] = zz[k] - 1.f; }
-      else { e[k] = softplus_f(zz[k]); al[k] = e[k] + 1.f; }
-      ed[k] = ev_in ? ev_in[(n * s.K + k) * s.V + v] : e[k];
+      else { e[k] = softplus_fast(zz[k]); al[k] = e[k] + 1.f; }
+      ed[k] = ev_in ? ev_in[(n * K + k) * s.V + v] : e[k];
     } else { e[k] = 0.f; al[k] = 0.f; ed[k] = 0.f; }
   }
 }
@@ -102,11 +170,11 @@ __device__ __forceinline__ void softmax_k(const float* ed, int K, float* prob) {
 // ----------------------------------------------------------------- forward
 // acc[0] = sum of per-voxel terms; acc[1+k], acc[1+MAXK+k], acc[1+2MAXK+k] = the three per-class sums of
 // the dice term: (I, P, R) for the soft dice of CRIT_DCE, (TP, FP, FN) for the Tversky dice of CRIT_DCEU.
-template <typename T, int KIND>
+template <typename T, int KIND, int KT>
 __global__ void __launch_bounds__(256)
 k_crit_fwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_in, const void* __restrict__ labels, int ldt,
            EvidParams p, float* __restrict__ evidence_out, float* __restrict__ per_voxel_out, double* __restrict__ partial) {
-  const int K = s.K;
+  const int K = KT ? KT : s.K;
   const int64_t NV = s.N * s.V;
   float acc[EV_NACC];
 #pragma unroll
@@ -115,7 +183,7 @@ k_crit_fwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NV; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / s.V, v = i % s.V;
     float zz[EV_MAXK], e[EV_MAXK], al[EV_MAXK], ed[EV_MAXK];
-    load_voxel<T>(in, ev_in, s, p, n, v, zz, e, al, ed);
+    load_voxel<T, KT>(in, ev_in, s, p, n, v, zz, e, al, ed);
     float S = 0.f;
 #pragma unroll
     for (int k = 0; k < EV_MAXK; ++k) {
@@ -132,8 +200,10 @@ k_crit_fwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
 #pragma unroll
       for (int k = 0; k < EV_MAXK; ++k) {
         if (k < K) {
-          sum_lg += lgamma_f(al[k]);
-          kl_sum = fmaf(al[k] - 1.f, digamma_f(al[k]) - psiS, kl_sum);
+          float ps, lg;
+          psi_lgamma_f(al[k], ps, lg);
+          sum_lg += lg;
+          kl_sum = fmaf(al[k] - 1.f, ps - psiS, kl_sum);
         }
       }
       pv = lgamma_f(S) - sum_lg - lgK + kl_sum;
@@ -143,16 +213,19 @@ k_crit_fwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
 #pragma unroll
       for (int k = 0; k < EV_MAXK; ++k) if (k == y) { e_y = e[k]; a_y = al[k]; }
       const float St = S - e_y;            // strength of alpha~ (label class reset to 1)
-      const float psiSt = digamma_f(St);
+      float psiSt, lgSt;
+      psi_lgamma_f(St, psiSt, lgSt);
       float sum_lg = 0.f, kl_sum = 0.f;
 #pragma unroll
       for (int k = 0; k < EV_MAXK; ++k) {
         if (k < K && k != y) {
-          sum_lg += lgamma_f(al[k]);
-          kl_sum = fmaf(e[k], digamma_f(al[k]) - psiSt, kl_sum);
+          float ps, lg;
+          psi_lgamma_f(al[k], ps, lg);
+          sum_lg += lg;
+          kl_sum = fmaf(e[k], ps - psiSt, kl_sum);
         }
       }
-      const float kl = lgamma_f(St) - sum_lg - lgK + kl_sum;
+      const float kl = lgSt - sum_lg - lgK + kl_sum;
       if (KIND == CRIT_MSE) {
         // criterions.py:144-154: sum (label - alpha/S)^2 + sum alpha(S-alpha)/(S^2 (S+1))
         float A = 0.f, B = 0.f;
@@ -251,20 +324,20 @@ __host__ __device__ inline Tversky tversky(double TP, double FP, double FN) {
 
 __global__ void k_evid_finalize(const double* __restrict__ partial, int blocks, int K, double NV, int kind, float a_au,
                                 float* __restrict__ scal) {
-  // 256 threads: accumulator i = tid % 32, block slice = tid / 32; slices combined in a fixed order
+  // 1024 threads: accumulator i = tid % 32, block slice = tid / 32; slices combined in a fixed order
   __shared__ double tot[EV_NACC];
-  __shared__ double red[8][32];
+  __shared__ double red[32][32];
   {
     const int i = threadIdx.x & 31, sl = threadIdx.x >> 5;
     double a = 0.0;
     if (i < EV_NACC)
-      for (int b = sl; b < blocks; b += 8) a += partial[(int64_t)b * EV_NACC + i];
+      for (int b = sl; b < blocks; b += 32) a += partial[(int64_t)b * EV_NACC + i];
     red[sl][i] = a;
   }
   __syncthreads();
   if (threadIdx.x < EV_NACC) {
     double a = 0.0;
-    for (int sl = 0; sl < 8; ++sl) a += red[sl][threadIdx.x];
+    for (int sl = 0; sl < 32; ++sl) a += red[sl][threadIdx.x];
     tot[threadIdx.x] = a;
   }
   __syncthreads();
@@ -291,13 +364,13 @@ __global__ void k_evid_finalize(const double* __restrict__ partial, int blocks, 
 // ---------------------------------------------------------------- backward
 // d_in = d loss / d input (logits: chain through softplus; alpha in raw mode).  In raw mode with a
 // separate dice tensor, the dice term's gradient goes to d_ev_in instead.
-template <typename T, int KIND>
+template <typename T, int KIND, int KT>
 __global__ void __launch_bounds__(256)
 k_crit_bwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_in, const void* __restrict__ labels, int ldt,
            EvidParams p, const float* __restrict__ scal, const float* __restrict__ grad_loss,
            const float* __restrict__ grad_pv, const float* __restrict__ grad_dice, const float* __restrict__ grad_ev,
            T* __restrict__ d_in, float* __restrict__ d_ev_in) {
-  const int K = s.K;
+  const int K = KT ? KT : s.K;
   const int64_t NV = s.N * s.V;
   // dice coefficients.  CRIT_DCE: dL/de_k(v) = c1_k - [y=k]*c0_k.   CRIT_DCEU: dL/dprob_k(v) = [y=k] ? c0_k : c1_k.
   float c0[EV_MAXK], c1[EV_MAXK];
@@ -325,7 +398,7 @@ k_crit_bwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NV; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / s.V, v = i % s.V;
     float zz[EV_MAXK], e[EV_MAXK], al[EV_MAXK], ed[EV_MAXK];
-    load_voxel<T>(in, ev_in, s, p, n, v, zz, e, al, ed);
+    load_voxel<T, KT>(in, ev_in, s, p, n, v, zz, e, al, ed);
     float S = 0.f;
 #pragma unroll
     for (int k = 0; k < EV_MAXK; ++k) if (k < K) S += al[k];
@@ -416,18 +489,26 @@ k_crit_bwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
       }
     }
     T* out = d_in + n * s.sN + v * s.sV;
+    float rr[EV_MAXK];
 #pragma unroll
     for (int k = 0; k < EV_MAXK; ++k) {
+      rr[k] = 0.f;
       if (k < K) {
         float r = d[k];
         if (d_ev_in) d_ev_in[(n * K + k) * s.V + v] = dd[k];
         else r += dd[k];
         if (!p.raw) {
           if (grad_ev) r += grad_ev[(n * K + k) * s.V + v];
-          r *= dsoftplus_f(zz[k]);
+          r *= dsoftplus_fast(zz[k]);
         }
-        st(out + k * s.sK, r);
+        rr[k] = r;
       }
+    }
+    if (KT == 4 && s.vec) {
+      store4(out, rr);
+    } else {
+#pragma unroll
+      for (int k = 0; k < EV_MAXK; ++k) if (k < K) st(out + k * s.sK, rr[k]);
     }
   }
 }
@@ -445,7 +526,7 @@ k_evid_infer(const T* __restrict__ z, EvidShape s, float* __restrict__ evidence_
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NV; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / s.V, v = i % s.V;
     float zz[EV_MAXK];
-    load_logits<T>(z, s, n, v, zz);
+    load_logits<T, 0>(z, s, n, v, zz);
     float a[EV_MAXK];
     float S = 0.f;
 #pragma unroll
@@ -510,6 +591,15 @@ static bool crit_args_ok(const devis_evid_params* p, const void* in, const void*
   return true;
 }
 
+static int evid_vec(const void* p, int64_t sN, int64_t sV, int64_t sK, int64_t K, int dtype) {
+  const size_t es = dtype == DEVIS_F32 ? 4 : 2;
+  return K == 4 && sK == 1 && sV == 4 && sN % 4 == 0 && ((size_t)p % (4 * es)) == 0;
+}
+
+#define DEVIS_DISPATCH_KT(K, ...)                         \
+  if ((K) == 4) { constexpr int KT = 4; __VA_ARGS__; }    \
+  else { constexpr int KT = 0; __VA_ARGS__; }
+
 #define DEVIS_DISPATCH_KIND(kind, ...)                                              \
   switch (kind) {                                                                   \
     case CRIT_DCE: { constexpr int KIND = CRIT_DCE; __VA_ARGS__; } break;           \
@@ -527,14 +617,14 @@ int devis_evid_crit_fwd(const devis_evid_params* p, const void* in, int64_t sN, 
   if (scal && (!ws || ws_bytes < devis_evid_workspace_bytes(N, V, K))) return ws ? DEVIS_ERR_WORKSPACE : DEVIS_ERR_BAD_ARG;
   if (evidence_in && !p->input_kind) return DEVIS_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const EvidShape sh = {sN, sV, sK, N, V, (int)K};
+  const EvidShape sh = {sN, sV, sK, N, V, (int)K, evid_vec(in, sN, sV, sK, K, dtype)};
   const EvidParams ep = {p->input_kind, p->disentangle, p->lambda, p->a_au, p->eps};
   const unsigned blocks = ev_grid(N * V);
   double* part = scal ? (double*)ws : nullptr;
-  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, hipLaunchKernelGGL((k_crit_fwd<T, KIND>), dim3(blocks), dim3(256), 0, s, (const T*)in, sh, evidence_in, labels, label_dtype, ep, evidence_out, per_voxel_out, part)));
+  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, DEVIS_DISPATCH_KT(K, hipLaunchKernelGGL((k_crit_fwd<T, KIND, KT>), dim3(blocks), dim3(256), 0, s, (const T*)in, sh, evidence_in, labels, label_dtype, ep, evidence_out, per_voxel_out, part))));
   int rc = launch_status();
   if (rc || !scal) return rc;
-  hipLaunchKernelGGL(k_evid_finalize, dim3(1), dim3(256), 0, s, (const double*)ws, (int)blocks, (int)K, (double)(N * V), p->kind, p->a_au, scal);
+  hipLaunchKernelGGL(k_evid_finalize, dim3(1), dim3(1024), 0, s, (const double*)ws, (int)blocks, (int)K, (double)(N * V), p->kind, p->a_au, scal);
   return launch_status();
 }
 
@@ -548,9 +638,9 @@ int devis_evid_crit_bwd(const devis_evid_params* p, const void* in, int64_t sN, 
   if (has_dice && !scal) return DEVIS_ERR_BAD_ARG;
   if ((evidence_in != nullptr) != (d_evidence_in != nullptr)) return DEVIS_ERR_BAD_ARG;
   if (evidence_in && (!p->input_kind || !has_dice)) return DEVIS_ERR_BAD_ARG;
-  const EvidShape sh = {sN, sV, sK, N, V, (int)K};
+  const EvidShape sh = {sN, sV, sK, N, V, (int)K, evid_vec(in, sN, sV, sK, K, dtype) && evid_vec(d_in, sN, sV, sK, K, dtype)};
   const EvidParams ep = {p->input_kind, p->disentangle, p->lambda, p->a_au, p->eps};
-  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, hipLaunchKernelGGL((k_crit_bwd<T, KIND>), dim3(ev_grid(N * V)), dim3(256), 0, (hipStream_t)stream, (const T*)in, sh, evidence_in, labels, label_dtype, ep, scal, grad_loss, grad_pv, grad_dice, grad_ev, (T*)d_in, d_evidence_in)));
+  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, DEVIS_DISPATCH_KT(K, hipLaunchKernelGGL((k_crit_bwd<T, KIND, KT>), dim3(ev_grid(N * V)), dim3(256), 0, (hipStream_t)stream, (const T*)in, sh, evidence_in, labels, label_dtype, ep, scal, grad_loss, grad_pv, grad_dice, grad_ev, (T*)d_in, d_evidence_in))));
   return launch_status();
 }
 
@@ -580,7 +670,7 @@ int devis_evid_infer(const void* logits, int64_t sN, int64_t sV, int64_t sK, int
   Thr thr;
   thr.n = umask ? n_thr : 0;
   for (int j = 0; j < 16; ++j) thr.t[j] = (j < thr.n) ? thresholds_host[j] : 0.f;
-  const EvidShape sh = {sN, sV, sK, N, V, (int)K};
+  const EvidShape sh = {sN, sV, sK, N, V, (int)K, 0};
   DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_evid_infer<T>, dim3(ev_grid(N * V)), dim3(256), 0, (hipStream_t)stream, (const T*)logits, sh, evidence_out, pred, u, mne, umask, thr));
   return launch_status();
 }

@@ -52,6 +52,38 @@ __global__ void k_repack_dgrad(const T* __restrict__ src, T* __restrict__ dst, i
   dst[i] = src[(co * Tn + (Tn - 1 - tf)) * Cin + ci];
 }
 
+// All weights of a model in one launch: block b handles DEVIS_PACK_CHUNK output elements of item
+// chunks[b].x starting at element chunks[b].y.  src is always the fp32 PyTorch tensor.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pack_batch(const devis_pack_item* __restrict__ items, const int2* __restrict__ chunks) {
+  const int2 ch = chunks[blockIdx.x];
+  const devis_pack_item it = items[ch.x];
+  const int64_t R = it.rows, Cc = it.cols, Tn = it.taps;
+  const int64_t total = R * Cc * Tn;
+  T* dst = reinterpret_cast<T*>(it.dst);
+#pragma unroll
+  for (int k = 0; k < DEVIS_PACK_CHUNK / 256; ++k) {
+    const int64_t i = (int64_t)ch.y + k * 256 + threadIdx.x;
+    if (i >= total) return;
+    int64_t si;
+    if (it.mode == DEVIS_PACK_CONV) {               // src [co][ci][t] -> dst [co][t][ci]
+      const int64_t ci = i % Cc, t = (i / Cc) % Tn, co = i / (Cc * Tn);
+      si = (co * Cc + ci) * Tn + t;
+    } else if (it.mode == DEVIS_PACK_CONV_DGRAD) {  // src [co][ci][t] -> dst [ci][T-1-t][co]
+      const int64_t co = i % R, tf = (i / R) % Tn, ci = i / (R * Tn);
+      si = (co * Cc + ci) * Tn + (Tn - 1 - tf);
+    } else if (it.mode == DEVIS_PACK_CONVT) {       // src [ci][co][t] -> dst [t][co][ci]
+      const int64_t ci = i % R, co = (i / R) % Cc, t = i / (R * Cc);
+      si = (ci * Cc + co) * Tn + t;
+    } else {                                        // src [ci][co][t] -> dst [ci][t][co]
+      const int64_t co = i % Cc, t = (i / Cc) % Tn, ci = i / (Cc * Tn);
+      si = (ci * Cc + co) * Tn + t;
+    }
+    st(dst + i, it.src[si]);
+  }
+}
+
 }  // namespace devis
 
 using namespace devis;
@@ -84,6 +116,13 @@ int devis_pack_convT_weight(const float* w, void* dst, int64_t Cin, int64_t Cout
   if (!w || !dst || Cout <= 0 || Cin <= 0 || Tn <= 0) return DEVIS_ERR_BAD_ARG;
   const int64_t n = Cout * Cin * Tn;
   DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_convT<T>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (T*)dst, Cin, Cout, Tn));
+  return launch_status();
+}
+
+int devis_pack_weights_batch(const devis_pack_item* items_dev, const int32_t* chunks_dev, int64_t n_chunks, int dtype,
+                             void* stream) {
+  if (!items_dev || !chunks_dev || n_chunks <= 0 || n_chunks > 0x7fffffff) return DEVIS_ERR_BAD_ARG;
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_batch<T>, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, items_dev, reinterpret_cast<const int2*>(chunks_dev)));
   return launch_status();
 }
 

@@ -116,6 +116,54 @@ def pack_convT_weight(w: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+class WeightPacker:
+    """Every conv / transposed-conv weight of a model re-packed by ONE launch per step
+    (devis_pack_weights_batch): forward layout [Cout][T][Cin] and, in bf16, the dgrad layouts the MFMA
+    kernels take.  The device tables are built once and stay valid while the parameters keep their addresses."""
+
+    def __init__(self, entries, dtype: torch.dtype, device: torch.device):
+        # entries: [(name, fp32 weight tensor, "conv" | "convT")]
+        import numpy as np
+        self.key = tuple(w.data_ptr() for _, w, _ in entries) + (dtype,)
+        want_d = dtype == torch.bfloat16
+        plan, off = [], 0
+        for name, w, kind in entries:
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise _lib.DevisError("WeightPacker needs contiguous fp32 parameters (%s)" % name)
+            a, b = int(w.shape[0]), int(w.shape[1])
+            t = w.numel() // (a * b)
+            n = a * b * t
+            if kind == "conv":          # w [Cout][Cin][T]
+                shapes = [(_lib.PACK_CONV, (a, t, b))] + ([(_lib.PACK_CONV_DGRAD, (b, t, a))] if want_d else [])
+            else:                       # w [Cin][Cout][T]
+                shapes = [(_lib.PACK_CONVT, (t, b, a))] + ([(_lib.PACK_CONVT_DGRAD, (a, t * b))] if want_d else [])
+            for mode, shape in shapes:
+                plan.append((name, w, a, b, t, mode, shape, off, n))
+                off += (n + 7) // 8 * 8         # 16-byte aligned views
+        self.arena = torch.empty((max(off, 8),), dtype=dtype, device=device)
+        es = self.arena.element_size()
+        items = np.zeros(len(plan), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
+                                                    ("taps", "<i4"), ("mode", "<i4")]))
+        chunks = []
+        self.views = {}
+        for i, (name, w, a, b, t, mode, shape, o, n) in enumerate(plan):
+            items[i] = (w.data_ptr(), self.arena.data_ptr() + o * es, a, b, t, mode)
+            chunks += [(i, st) for st in range(0, n, _lib.PACK_CHUNK)]
+            view = self.arena[o:o + n].view(shape)
+            slot = self.views.setdefault(name, [None, None])
+            slot[0 if mode in (_lib.PACK_CONV, _lib.PACK_CONVT) else 1] = view
+        self.items = torch.from_numpy(items.view(np.uint8).copy()).to(device)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32).to(device)
+        self.n_chunks = len(chunks)
+        self.dtype = dtype
+
+    def pack(self):
+        """-> {name: [w_packed, w_dgrad | None]} for the CURRENT parameter values."""
+        check(_lib.load().devis_pack_weights_batch(_p(self.items), _p(self.chunks), self.n_chunks, dt_code(self.dtype),
+                                                   _stream()), "pack_weights_batch")
+        return self.views
+
+
 # -------------------------------------------------------------------- conv
 class ConvGeom:
     """kernel / stride / padding of one conv layer, each a (d, h, w) triple."""
@@ -168,8 +216,10 @@ def conv_fwd(x1: Tensor, x2: Optional[Tensor], wp: Tensor, bias: Optional[Tensor
     return y
 
 
-def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, residual: Optional[Tensor] = None):
-    """-> (dx1, dx2|None): gradient w.r.t. the conv's (post-prologue) inputs."""
+def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, residual: Optional[Tensor] = None,
+               wd: Optional[Tensor] = None):
+    """-> (dx1, dx2|None): gradient w.r.t. the conv's (post-prologue) inputs.  `wd`: the dgrad packing
+    of the weight when the caller already has it (WeightPacker), else it is derived from `wp` here."""
     _need_cuda(dy, wp)
     n = in_shape1[0]
     c1 = in_shape1[-1]
@@ -180,9 +230,8 @@ def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, r
     dx1 = torch.empty(tuple(in_shape1), dtype=dy.dtype, device=dy.device)
     dx2 = torch.empty(tuple(in_shape1[:-1]) + (c2,), dtype=dy.dtype, device=dy.device) if c2 else None
     lib = _lib.load()
-    wd = None
-    if dy.dtype == torch.bfloat16 and ((c2 == 0 and geom.k == (3, 3, 3) and geom.s in ((1, 1, 1), (2, 2, 2)))
-                                       or geom.k == (1, 1, 1)):
+    if wd is None and dy.dtype == torch.bfloat16 and ((c2 == 0 and geom.k == (3, 3, 3) and geom.s in ((1, 1, 1), (2, 2, 2)))
+                                                      or geom.k == (1, 1, 1)):
         # tap-flipped [Cin][T][Cout] packing: dgrad runs on the MFMA forward kernel
         wd = torch.empty((wp.shape[2], wp.shape[1], wp.shape[0]), dtype=wp.dtype, device=wp.device)
         check(lib.devis_repack_conv_weight_dgrad(_p(wp), _p(wd), wp.shape[0], wp.shape[2], wp.shape[1],
@@ -234,13 +283,12 @@ def convT_fwd(x: Tensor, wp: Tensor, bias: Optional[Tensor], k) -> Tensor:
     return y
 
 
-def convT_dgrad(dy: Tensor, wp: Tensor, k, x_shape) -> Tensor:
+def convT_dgrad(dy: Tensor, wp: Tensor, k, x_shape, wt: Optional[Tensor] = None) -> Tensor:
     _need_cuda(dy, wp)
     d = _tdesc(x_shape, wp.shape[2], wp.shape[1], k, dy.dtype)
     dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
-    wt = None
-    if dy.dtype == torch.bfloat16:
+    if wt is None and dy.dtype == torch.bfloat16:
         t, co, ci = wp.shape
         wt = torch.empty((ci, t * co), dtype=wp.dtype, device=wp.device)
         check(lib.devis_repack_conv_weight_dgrad(_p(wp), _p(wt), t * co, ci, 1, dt_code(wp.dtype), _stream()),

@@ -87,12 +87,28 @@ class AverageMeter(object):
         self.avg = self.sum / self.count
 
 
+_gc_frozen = False
+
+
+def freeze_gc() -> None:
+    """Move everything allocated so far (torch, the model) out of the cyclic GC's reach.  A full Python
+    collection walks millions of long-lived objects and stalls the launch thread for ~100 ms - ten training
+    steps on MI355X; after this, collections only look at what the steps themselves allocate."""
+    global _gc_frozen
+    if not _gc_frozen:
+        import gc
+        gc.collect()
+        gc.freeze()
+        _gc_frozen = True
+
+
 def train(args, model, optimizer, epoch, train_loader, reducer=None, log=print):
     """One epoch; same order of operations as trainUMIS.py:239-263.  `reducer` (devis_amd.parallel)
     averages gradients across ranks.  The per-iteration loss print is kept (it is a host sync)."""
     model.train()
     meter = AverageMeter()
     step = 0
+    freeze_gc()
     for data in train_loader:
         adjust_learning_rate(optimizer, epoch, args.end_epochs, args.lr)
         step += 1

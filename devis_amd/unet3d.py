@@ -70,15 +70,20 @@ class _DeBlock(nn.Module):           # UNet3DZoo.py:145-165
 class _Run:
     """One forward (and, if taped, backward) pass of the 3-D U-Net over channels-last tensors."""
 
-    def __init__(self, params: Dict[str, Tensor], buffers: Dict[str, Tensor], dtype, training: bool, tape: bool):
+    def __init__(self, params: Dict[str, Tensor], buffers: Dict[str, Tensor], dtype, training: bool, tape: bool,
+                 packed: Dict[str, list]):
         self.P, self.B = params, buffers
+        self.W = packed                       # name.weight -> [w_packed, w_dgrad | None] (ops.WeightPacker)
         self.dtype, self.training, self.taping = dtype, training, tape
         self.tape: List = []
         self.grads: Dict[str, Tensor] = {}
 
     # ---- helpers
     def _w(self, name):
-        return ops.pack_conv_weight(self.P[name + ".weight"], self.dtype)
+        return self.W[name + ".weight"][0]
+
+    def _wd(self, name):
+        return self.W[name + ".weight"][1]
 
     def _push(self, *entry):
         if self.taping:
@@ -124,7 +129,7 @@ class _Run:
     def de_up_cat(self, name, x, prev):
         w1 = self._w(name + ".conv1")
         t = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G1)
-        wt = ops.pack_convT_weight(self.P[name + ".conv2.weight"], self.dtype)
+        wt = self._w(name + ".conv2")
         up = ops.convT_fwd(t, wt, self.P[name + ".conv2.bias"], (2, 2, 2))
         w3 = self._w(name + ".conv3")
         y = ops.conv_fwd(prev, up, w3, self.P[name + ".conv3.bias"], G1)     # virtual cat((prev, up))
@@ -153,19 +158,19 @@ class _Run:
         _, name, x, wp, geom = e
         g = self.grads
         g[name + ".weight"], g[name + ".bias"] = ops.conv_wgrad(x, None, dy, geom, self.P[name + ".weight"].shape)
-        return ops.conv_dgrad(dy, wp, geom, x.shape, residual=skip)[0] if need_dx else None
+        return ops.conv_dgrad(dy, wp, geom, x.shape, residual=skip, wd=self._wd(name))[0] if need_dx else None
 
     def _en_bwd(self, e, dout):
         _, name, x, h, st1, st2, w1, w2 = e
         g, P = self.grads, self.P
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
             h, None, dout, G3, P[name + ".conv2.weight"].shape, st2[0], st2[1])
-        da = ops.conv_dgrad(dout, w2, G3, h.shape)[0]
+        da = ops.conv_dgrad(dout, w2, G3, h.shape, wd=self._wd(name + ".conv2"))[0]
         dh, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
             da, h, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 8, False)
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
             x, None, dh, G3, P[name + ".conv1.weight"].shape, st1[0], st1[1])
-        da = ops.conv_dgrad(dh, w1, G3, x.shape)[0]
+        da = ops.conv_dgrad(dh, w1, G3, x.shape, wd=self._wd(name + ".conv1"))[0]
         dx, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
             da, x, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 8, False, extra=dout)
         return dx
@@ -177,25 +182,25 @@ class _Run:
             dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, True)
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
             h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1])
-        da = ops.conv_dgrad(dh2, w2, G3, h1.shape)[0]
+        da = ops.conv_dgrad(dh2, w2, G3, h1.shape, wd=self._wd(name + ".conv2"))[0]
         dh1, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
             da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, True)
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
             x, None, dh1, G3, P[name + ".conv1.weight"].shape)
-        return ops.conv_dgrad(dh1, w1, G3, x.shape, residual=dout)[0]
+        return ops.conv_dgrad(dh1, w1, G3, x.shape, residual=dout, wd=self._wd(name + ".conv1"))[0]
 
     def _up_bwd(self, e, dy):
         _, name, x, prev, t, up, w1, wt, w3 = e
         g, P = self.grads, self.P
         g[name + ".conv3.weight"], g[name + ".conv3.bias"] = ops.conv_wgrad(
             prev, up, dy, G1, P[name + ".conv3.weight"].shape)
-        dprev, dup = ops.conv_dgrad(dy, w3, G1, prev.shape, up.shape[-1])
+        dprev, dup = ops.conv_dgrad(dy, w3, G1, prev.shape, up.shape[-1], wd=self._wd(name + ".conv3"))
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.convT_wgrad(
             t, dup, (2, 2, 2), P[name + ".conv2.weight"].shape)
-        dt = ops.convT_dgrad(dup, wt, (2, 2, 2), t.shape)
+        dt = ops.convT_dgrad(dup, wt, (2, 2, 2), t.shape, wt=self._wd(name + ".conv2"))
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
             x, None, dt, G1, P[name + ".conv1.weight"].shape)
-        dx = ops.conv_dgrad(dt, w1, G1, x.shape)[0]
+        dx = ops.conv_dgrad(dt, w1, G1, x.shape, wd=self._wd(name + ".conv1"))[0]
         return dx, dprev
 
     def backward(self, dlogits: Tensor, need_dx: bool):
@@ -225,7 +230,7 @@ class _Unet3dFn(torch.autograd.Function):
         names = model._param_names
         P = dict(zip(names, params))
         taping = any(ctx.needs_input_grad)
-        run = _Run(P, dict(model.named_buffers()), model.compute_dtype, model.training, taping)
+        run = _Run(P, dict(model.named_buffers()), model.compute_dtype, model.training, taping, model._packed(P))
         logits = run.forward(ops.to_channels_last(x, model.compute_dtype))
         ctx.run, ctx.names = run, names
         ctx.need_dx = ctx.needs_input_grad[1]
@@ -288,6 +293,18 @@ class Unet(nn.Module):
         self.compute_dtype = compute_dtype
         self.num_classes = num_classes
         self._param_names = [n for n, _ in self.named_parameters()]
+        self._conv_modules = [(n + ".weight", m) for n, m in self.named_modules()
+                              if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d))]
+        self._packer = None
+
+    def _packed(self, P: Dict[str, Tensor]):
+        """All conv weights in the kernels' layouts, one launch (rebuilt tables only if a parameter moved)."""
+        ent = [(n, P[n].detach(), "convT" if isinstance(m, nn.ConvTranspose3d) else "conv")
+               for n, m in self._conv_modules]
+        key = tuple(w.data_ptr() for _, w, _ in ent) + (self.compute_dtype,)
+        if self._packer is None or self._packer.key != key:
+            self._packer = ops.WeightPacker(ent, self.compute_dtype, ent[0][1].device)
+        return self._packer.pack()
 
     def forward_channels_last(self, x: Tensor) -> Tensor:
         if x.dim() != 5 or x.shape[1] != self.InitConv.conv.in_channels:

@@ -55,6 +55,25 @@ int devis_pack_conv_weight(const float* w, void* dst, int64_t Cout, int64_t Cin,
 /* nn.ConvTranspose{2,3}d.weight [Cin][Cout][T] fp32 -> [T][Cout][Cin] dtype */
 int devis_pack_convT_weight(const float* w, void* dst, int64_t Cin, int64_t Cout, int64_t T, int dtype, void* stream);
 
+/* Every weight of a model packed by ONE launch (the per-layer calls above cost a launch each, ~90 per
+ * step for the 3-D U-Net).  `items_dev` (device memory) lists the tensors; `chunks_dev` (device memory,
+ * n_chunks pairs of int32) assigns each block one item and the first of its DEVIS_PACK_CHUNK output
+ * elements.  Both tables stay valid while the parameters keep their addresses, so the caller builds them once.
+ *   DEVIS_PACK_CONV        src [rows=Cout][cols=Cin][taps]  -> dst [Cout][taps][Cin]   (devis_pack_conv_weight)
+ *   DEVIS_PACK_CONV_DGRAD  same src                         -> dst [Cin][taps][Cout], taps reversed
+ *                                                              (= devis_repack_conv_weight_dgrad of the above)
+ *   DEVIS_PACK_CONVT       src [rows=Cin][cols=Cout][taps]  -> dst [taps][Cout][Cin]   (devis_pack_convT_weight)
+ *   DEVIS_PACK_CONVT_DGRAD same src                         -> dst [Cin][taps][Cout]   (w_t of devis_convT_dgrad) */
+enum { DEVIS_PACK_CONV = 0, DEVIS_PACK_CONV_DGRAD = 1, DEVIS_PACK_CONVT = 2, DEVIS_PACK_CONVT_DGRAD = 3 };
+#define DEVIS_PACK_CHUNK 1024
+typedef struct devis_pack_item {
+  const float* src;
+  void* dst;
+  int32_t rows, cols, taps, mode;
+} devis_pack_item;
+int devis_pack_weights_batch(const devis_pack_item* items_dev, const int32_t* chunks_dev, int64_t n_chunks,
+                             int dtype, void* stream);
+
 /* ------------------------------------------------------------------ conv -- */
 typedef struct devis_conv_desc {
   int64_t N;
