@@ -189,17 +189,17 @@ def main():
     }
     if rank == 0:
         probe = kernel_probe(a.batch, S, dtype)
-        # Dominant kernel of the step by summed time (profiles/r01_*kernel_stats.csv): the 3x3x3 conv at 16
-        # channels and full resolution, k_conv3_mfma<16,16,8,8,16,1> (forward and, with tap-flipped weights,
+        # Dominant kernel family of the step by summed time (profiles/r01_*kernel_stats.csv): the 3x3x3 conv at
+        # 16 channels and full resolution, k_conv3_c16_march<8,32,...> (forward and, with tap-flipped weights,
         # dgrad).  Its arithmetic intensity (27*16*16*2 FLOP per 64 B = 216 FLOP/B) is below the MI355X ridge
         # (2.5 PF / 8 TB/s = 312), so the roof that binds it is HBM; the MFMA fraction is reported next to it.
         name = "conv3d_fwd_c16"
         t, flops, alg_bytes = probe[name]
-        # HBM bytes per launch from the PMC passes in profiles/r01_pmc_{fetch,write}_size_conv_c16.csv
-        # (B=2, 128^3): FETCH_SIZE 81,950 KB x2 (gfx950 reports half of a wide coalesced read,
+        # HBM bytes per launch from the PMC passes in profiles/r01_pmc_{fetch,write}_size_march_c16.csv
+        # (B=2, 128^3): FETCH_SIZE 70,937 KB x2 (gfx950 reports half of a wide coalesced read,
         # MI355X_MICROARCH.md "HBM") + WRITE_SIZE 131,072 KB; scaled linearly with the voxel count.
-        traffic = (2 * 81950.3 + 131072.0) * 1024 * (a.batch * S ** 3) / (2 * 128 ** 3) if dtype == torch.bfloat16 else None
-        out["roofline"] = {"kernel": "k_conv3_mfma<16,16,8,8,16,1> (" + name + ")", "bound": "hbm",
+        traffic = (2 * 70937.5 + 131072.0) * 1024 * (a.batch * S ** 3) / (2 * 128 ** 3) if dtype == torch.bfloat16 else None
+        out["roofline"] = {"kernel": "k_conv3_c16_march<8,32,PRO> (" + name + ")", "bound": "hbm",
                            "achieved": alg_bytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": alg_bytes / t / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                            "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
