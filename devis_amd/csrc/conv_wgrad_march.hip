@@ -288,4 +288,363 @@ int wgrad3_c16_march(const devis_conv_desc* d, const void* x, const float* sc, c
   return launch_wgrad_reduce(a.part, a.bpart, (int)blocks, 16, 16, (int)d->C1, dw, dbias, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 32 x 32-channel slabs of the wider layers (Cin, Cout multiples of 32; stride 1): the same walk with
+// an (8 x 16) column, 64-byte voxel rows in LDS (both 32-byte halves XOR-swizzled for the transposing
+// reads), 7 taps x 2 x 2 accumulator tiles per wave.  grid = (columns x D chunks, cin slabs x cout slabs);
+// one partial of the whole [27][Cout][Cin] gradient per grid.x, each slab block writing its own part.
+struct WgSlabArgs {
+  const bf16* x;
+  const bf16* dy;
+  const float* sc;   // [N][Cin] or null
+  const float* sh;
+  float* part;       // [gx][27][Cout][Cin]
+  float* bpart;      // [gx][Cout] or null
+  int N, D, H, W, Cin, Cout;
+  int nth, ntw, ndc, DL;
+};
+
+__device__ __forceinline__ int img64(int u, int half) { return u * 64 + ((half ^ ((u >> 2) & 1)) << 5); }
+
+#ifdef DEVIS_PHASE_TIMING
+#define PHASE_MARK(i) { const long long now = clock64(); ph[i] += now - tmark; tmark = now; }
+#else
+#define PHASE_MARK(i)
+#endif
+
+// scheduling pattern of one unit: 8 x { 1 MFMA, n LDS reads }
+#define SLAB_INTERLEAVE(n)                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x100, n, 0);      \
+  }
+
+template <bool PRO>
+__global__ void __launch_bounds__(256)
+k_wgrad3_slab_march(WgSlabArgs a) {
+#ifdef DEVIS_PHASE_TIMING
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tmark = clock64();
+#endif
+  constexpr int TH = 8, TW = 16;
+  constexpr int HH = TH + 2, HW = TW + 2, HP = HH * HW;          // 180 voxels
+  constexpr int HWL = 24;                                        // LDS row pitch in voxels: a multiple of 8, so the
+                                                                 // swizzle bit of a read depends on (lane, kw) only
+  constexpr int NPT = (HP * 4 + 255) / 256;                      // 3
+  constexpr int PLB = HH * HWL * 64;                             // 15 KB per x plane
+  constexpr int R = 4;
+  constexpr int YPL = TH * TW * 64;                              // 8 KB per dy plane tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ys = smem + R * PLB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int nci = a.Cin / 32;
+  const int ci0 = (blockIdx.y % nci) * 32, co0 = (blockIdx.y / nci) * 32;
+
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int qq = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
+  }
+  const int twi = tile % a.ntw;
+  const int thi = (tile / a.ntw) % a.nth;
+  const int dci = (tile / (a.ntw * a.nth)) % a.ndc;
+  const int n = tile / (a.ntw * a.nth * a.ndc);
+  const int oh0 = thi * TH, ow0 = twi * TW;
+  const int d0 = dci * a.DL;
+  const int d1 = min(d0 + a.DL, a.D);
+  const size_t plane = (size_t)a.H * a.W;
+  const int piece = tid & 3;                                      // 8 channels of the slab's 32
+
+  unsigned goff[NPT], loff[NPT];
+  bool ok[NPT];
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int i = tid + k * 256;
+    const int u = i >> 2;
+    const int hh = u / HW, hw = u - hh * HW;
+    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+    ok[k] = i < HP * 4 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+    goff[k] = ok[k] ? (unsigned)((ih * a.W + iw) * a.Cin + ci0 + piece * 8) : (unsigned)ci0;
+    loff[k] = (unsigned)(img64(hh * HWL + hw, piece >> 1) + (piece & 1) * 16);
+  }
+  unsigned yoff[2], yl[2];
+  bool yok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = (tid + k * 256) >> 2;                           // voxel of the 8x16 tile, row-major
+    const int oh = oh0 + v / TW, ow = ow0 + v % TW;
+    yok[k] = oh < a.H && ow < a.W;
+    yoff[k] = yok[k] ? (unsigned)((oh * a.W + ow) * a.Cout + co0 + piece * 8) : (unsigned)co0;
+    yl[k] = (unsigned)(img64(v, piece >> 1) + (piece & 1) * 16);
+  }
+  float scv[8], shv[8];
+  if (PRO) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      scv[j] = a.sc[n * a.Cin + ci0 + piece * 8 + j];
+      shv[j] = a.sh[n * a.Cin + ci0 + piece * 8 + j];
+    }
+  }
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+  const bool do_bias = a.bpart != nullptr && ci0 == 0;
+
+  auto load_x = [&](int id, u32x4 (&rg)[NPT]) __attribute__((always_inline)) {
+    const int idc = min(max(id, 0), a.D - 1);
+    const bf16* xp = a.x + ((size_t)n * a.D + idc) * plane * a.Cin;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) rg[k] = *reinterpret_cast<const u32x4*>(xp + goff[k]);
+  };
+  auto store_x_piece = [&](int k, int id, int slot, u32x4 (&rg)[NPT]) __attribute__((always_inline)) {
+    const bool pin = id >= 0 && id < a.D;
+    u32x4 v = rg[k];
+    if (PRO) v = affine_relu8(v, scv, shv);
+    if (!(pin && ok[k])) v = (u32x4){0u, 0u, 0u, 0u};
+    if (k < NPT - 1 || tid + k * 256 < HP * 4) *reinterpret_cast<u32x4*>(smem + slot * PLB + loff[k]) = v;
+  };
+  auto store_x = [&](int id, int slot, u32x4 (&rg)[NPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) store_x_piece(k, id, slot, rg);
+  };
+  auto load_y = [&](int od, u32x4 (&rg)[2]) __attribute__((always_inline)) {
+    const int odc = min(od, a.D - 1);
+    const bf16* yp = a.dy + ((size_t)n * a.D + odc) * plane * a.Cout;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) rg[k] = *reinterpret_cast<const u32x4*>(yp + yoff[k]);
+  };
+  auto store_y_piece = [&](int k, int od, int buf, u32x4 (&rg)[2]) __attribute__((always_inline)) {
+    const bool pin = od < d1;
+    u32x4 v = rg[k];
+    if (!(pin && yok[k])) v = (u32x4){0u, 0u, 0u, 0u};
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bsum[2 * j] += bf_lo(v[j]); bsum[2 * j + 1] += bf_hi(v[j]); }
+    }
+    *reinterpret_cast<u32x4*>(ys + buf * YPL + yl[k]) = v;
+  };
+  auto store_y = [&](int od, int buf, u32x4 (&rg)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) store_y_piece(k, od, buf, rg);
+  };
+
+  {
+    u32x4 r0[NPT], r1[NPT], r2[NPT], y0[2];
+    load_x(d0 - 1, r0);
+    load_x(d0, r1);
+    load_x(d0 + 1, r2);
+    load_y(d0, y0);
+    store_x(d0 - 1, 0, r0);
+    store_x(d0, 1, r1);
+    store_x(d0 + 1, 2, r2);
+    store_y(d0, 0, y0);
+  }
+  __syncthreads();
+
+  f32x4 acc[7][2][2];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) acc[t][mo][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wv = 4 * g + q;                       // voxel column this lane addresses
+  // Lane part of every fragment address, computed once: with 8-voxel-aligned rows the XOR bit of voxel
+  // (row, wv + kw) is ((wv + kw) >> 2) & 1, so the K step and the row only add compile-time offsets.
+  int tkd[7], xl[7][2], ya[2];
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt) {
+    int t = wave + 4 * tt;
+    if (t > 26) t = 26;                           // phantom tap of wave 3: computed, never written
+    tkd[tt] = t / 9;
+    const int kh = (t / 3) % 3, col = wv + t % 3;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) xl[tt][mi] = (kh * HWL + col) * 64 + ((mi ^ ((col >> 2) & 1)) << 5) + p * 8;
+  }
+#pragma unroll
+  for (int mo = 0; mo < 2; ++mo) ya[mo] = wv * 64 + ((mo ^ ((wv >> 2) & 1)) << 5) + p * 8;
+  const bool last_real = wave + 24 < 27;
+
+  PHASE_MARK(4)
+  const int np = d1 - d0;
+  for (int it = 0; it < np; ++it) {
+    const int od = d0 + it;
+    u32x4 prex[NPT], prey[2];
+    load_x(od + 2, prex);
+    load_y(od + 1, prey);
+    __builtin_amdgcn_sched_barrier(0);
+    PHASE_MARK(0)
+
+    const char* yb[2];
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo) yb[mo] = ys + (it & 1) * YPL + ya[mo];
+    const char* xb[7][2];
+#pragma unroll
+    for (int tt = 0; tt < 7; ++tt)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) xb[tt][mi] = smem + ((it + tkd[tt]) & (R - 1)) * PLB + xl[tt][mi];
+
+    // K step s: rows 2s and 2s+1 of the tile, voxel column wv
+    auto read_a = [&](int s, bf16x8 (&af)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo) af[mo] = tr_pair_m(yb[mo] + (2 * s) * TW * 64, yb[mo] + (2 * s + 1) * TW * 64);
+    };
+    // unit (s, tg): taps tt = 2tg, 2tg+1 (tg = 3: tap 6 only)
+    auto read_b = [&](int s, int tg, bf16x8 (&bf)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int tt = 2 * tg + h;
+        if (tt < 7) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            bf[h][mi] = tr_pair_m(xb[tt][mi] + (2 * s) * HWL * 64, xb[tt][mi] + (2 * s + 1) * HWL * 64);
+        }
+      }
+    };
+    auto mma = [&](int tg, bf16x8 (&af)[2], bf16x8 (&bf)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int tt = 2 * tg + h;
+        if (tt < 7) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int mo = 0; mo < 2; ++mo)
+              acc[tt][mo][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mo], bf[h][mi], acc[tt][mo][mi], 0, 0, 0);
+        }
+      }
+    };
+    bf16x8 afA[2], afB[2], bA[2][2], bB[2][2];
+    read_a(0, afA);
+    read_b(0, 0, bA);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      // four units of this K step; fragments of the next unit are in flight under the MFMAs of the current one
+      bf16x8 (&af)[2] = (s & 1) ? afB : afA;
+      bf16x8 (&afn)[2] = (s & 1) ? afA : afB;
+      // each unit's MFMAs are issued with the next unit's fragment reads slotted between them (one MFMA,
+      // then the reads that fit under its 16 cycles), so neither the LDS queue nor the matrix pipe waits
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0, af, bA);
+      read_b(s, 1, bB);
+      SLAB_INTERLEAVE(1)
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1, af, bB);
+      read_b(s, 2, bA);
+      SLAB_INTERLEAVE(1)
+      __builtin_amdgcn_sched_barrier(0);
+      mma(2, af, bA);
+      read_b(s, 3, bB);
+      if (s + 1 < 4) read_a(s + 1, afn);
+      SLAB_INTERLEAVE(2)
+      __builtin_amdgcn_sched_barrier(0);
+      mma(3, af, bB);
+      if (s + 1 < 4) read_b(s + 1, 0, bA);
+      SLAB_INTERLEAVE(2)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    PHASE_MARK(1)
+    store_x(od + 2, (it + 3) & (R - 1), prex);
+    store_y(od + 1, (it + 1) & 1, prey);
+    PHASE_MARK(2)
+    __syncthreads();
+    PHASE_MARK(3)
+  }
+
+  // ---- partial results: D layout col = ci = lane&15, rows co = (lane>>4)*4 + j
+  float* part = a.part + (size_t)blockIdx.x * 27 * a.Cout * a.Cin;
+#pragma unroll
+  for (int tt = 0; tt < 7; ++tt) {
+    const int t = wave + 4 * tt;
+    if (tt < 6 || last_real) {
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int ci = ci0 + mi * 16 + (lane & 15);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int co = co0 + mo * 16 + g * 4 + j;
+            part[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[tt][mo][mi][j];
+          }
+        }
+    }
+  }
+  PHASE_MARK(5)
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);       // [256][8]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    // channel c = tid % 32 (piece c/8, element c%8) is held by threads k = c/8 (mod 4); 8 groups of 8 threads
+    // each, then the 8 group sums in order
+    float* red2 = red + 2048;                          // [8][32]
+    {
+      const int c = tid & 31, grp = tid >> 5, pc = c >> 3, j = c & 7;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += red[(pc + 4 * (grp * 8 + i)) * 8 + j];
+      red2[grp * 32 + c] = s;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += red2[i * 32 + tid];
+      a.bpart[(size_t)blockIdx.x * a.Cout + co0 + tid] = s;
+    }
+  }
+#ifdef DEVIS_PHASE_TIMING
+  PHASE_MARK(6)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+    long long* dbg = reinterpret_cast<long long*>(a.bpart + (size_t)gridDim.x * a.Cout) + wave * 8;
+    for (int i = 0; i < 8; ++i) dbg[i] = ph[i];
+  }
+#endif
+}
+
+// stride-1 3x3x3 with Cin, Cout multiples of 32 (<= 128), bf16.  query: only report the workspace size.
+int wgrad3_slab_march(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,
+                      float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t s, bool query, size_t* need) {
+  if (d->dtype != DEVIS_BF16 || d->C2 != 0 || d->SD != 1 || d->C1 % 32 || d->Cout % 32 || d->C1 > 128 || d->Cout > 128) return DEVIS_ERR_UNSUPPORTED;
+  if (d->OD != d->ID || d->OH != d->IH || d->OW != d->IW) return DEVIS_ERR_UNSUPPORTED;
+  if (d->IH * d->IW * (d->C1 > d->Cout ? d->C1 : d->Cout) >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
+  WgSlabArgs a;
+  a.N = (int)d->N; a.D = (int)d->OD; a.H = (int)d->OH; a.W = (int)d->OW; a.Cin = (int)d->C1; a.Cout = (int)d->Cout;
+  a.nth = (int)cdiv(a.H, 8); a.ntw = (int)cdiv(a.W, 16);
+  const int nslab = (a.Cin / 32) * (a.Cout / 32);
+  // D chunk: about 256 blocks in all (one per CU), never shorter than 4 planes (each chunk re-reads 2 halo
+  // planes and leaves one more partial for the reduction)
+  const int64_t cols = (int64_t)a.N * a.nth * a.ntw * nslab;
+  int dl = 32;
+  while (dl > 4 && cols * cdiv(a.D, dl) < 256) dl >>= 1;
+  {
+    static int dl_env = -1;
+    if (dl_env < 0) { const char* e = getenv("DEVIS_SLAB_DL"); dl_env = e ? atoi(e) : 0; }
+    if (dl_env > 0) dl = dl_env;
+  }
+  a.DL = dl;
+  a.ndc = (int)cdiv(a.D, dl);
+  const int64_t gx = (int64_t)a.N * a.ndc * a.nth * a.ntw;
+  if (gx > 0x7fffffff || nslab > 65535) return DEVIS_ERR_UNSUPPORTED;
+  const size_t part_bytes = (size_t)gx * 27 * a.Cout * a.Cin * sizeof(float);
+  const size_t total = part_bytes + (size_t)gx * a.Cout * sizeof(float);
+  if (query) { *need = total; return DEVIS_OK; }
+  if (!ws || ws_bytes < total) return DEVIS_ERR_WORKSPACE;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.sc = sc; a.sh = sh;
+  a.part = (float*)ws; a.bpart = dbias ? (float*)((char*)ws + part_bytes) : nullptr;
+  constexpr int LDS = 4 * 10 * 24 * 64 + 2 * 8 * 16 * 64;
+  const dim3 grid((unsigned)gx, (unsigned)nslab);
+  if (sc) hipLaunchKernelGGL((k_wgrad3_slab_march<true>), grid, dim3(256), LDS, s, a);
+  else hipLaunchKernelGGL((k_wgrad3_slab_march<false>), grid, dim3(256), LDS, s, a);
+  int rc = launch_status();
+  if (rc) return rc;
+  return launch_wgrad_reduce(a.part, a.bpart, (int)gx, a.Cout, a.Cin, a.Cin, dw, dbias, s);
+}
+
 }  // namespace devis

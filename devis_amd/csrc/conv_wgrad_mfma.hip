@@ -220,6 +220,8 @@ int launch_wgrad_reduce(const float* part, const float* bpart, int gx, int Cout,
 
 int wgrad3_c16_march(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,
                      float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t s, bool query, size_t* need);
+int wgrad3_slab_march(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,
+                      float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t s, bool query, size_t* need);
 
 static int wg_gx(int64_t ntiles, int nslab) {
   int64_t cap = 512 / nslab;
@@ -274,6 +276,10 @@ static int wgrad_dispatch(const devis_conv_desc* d, const void* x, const float* 
         if (rc2 == DEVIS_OK && other > *need) *need = other;
         return rc == DEVIS_OK ? rc : rc2;
       }
+    }
+    if (!no_march && ci % 32 == 0 && co % 32 == 0 && ci <= 128 && co <= 128) {
+      const int rc = wgrad3_slab_march(d, x, sc, sh, dy, dw, dbias, ws, ws_bytes, s, query, need);
+      if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
     }
     if (ci == 4 && co == 16) WG(16, 16, 4, 4, 1, true);
     if (ci == 16 && co == 16) WG(16, 16, 4, 4, 1, false);
