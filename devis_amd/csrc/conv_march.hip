@@ -196,19 +196,27 @@ k_conv3_c16_march(MarchArgs a) {
     };
     bf16x8 bA[NT], bB[NT];
     read_b(0, bA);
+    // chunk c's MFMAs are issued with chunk c+1's fragment reads slotted between them (1 MFMA, 1 read, ...)
+#define MARCH_INTERLEAVE                                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < NT; ++i_) {       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+  }
 #pragma unroll
     for (int c = 0; c < 14; c += 2) {
-      read_b(c + 1, bB);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bA[j], acc[j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (c + 2 < 14) read_b(c + 2, bA);
+      read_b(c + 1, bB);
+      MARCH_INTERLEAVE
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c + 1], bB[j], acc[j], 0, 0, 0);
+      if (c + 2 < 14) read_b(c + 2, bA);
+      MARCH_INTERLEAVE
       __builtin_amdgcn_sched_barrier(0);
     }
+#undef MARCH_INTERLEAVE
 
     // ---- epilogue of plane od
     bf16* yp = a.y + pbase;
