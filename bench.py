@@ -139,7 +139,7 @@ def main():
     model = TMSU(args)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=1e-5)     # trainUMIS.py:1394
-    reducer = GradientAllReducer(model.parameters()) if world > 1 else None
+    reducer = GradientAllReducer(model.parameters(), module=model) if world > 1 else None
     g = torch.Generator().manual_seed(1234 + rank)
     S = a.size
     x = torch.randn((a.batch, 4, S, S, S), generator=g).to(dev)

@@ -175,13 +175,14 @@ __global__ void __launch_bounds__(256)
 k_crit_fwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_in, const void* __restrict__ labels, int ldt,
            EvidParams p, float* __restrict__ evidence_out, float* __restrict__ per_voxel_out, double* __restrict__ partial) {
   const int K = KT ? KT : s.K;
-  const int64_t NV = s.N * s.V;
   float acc[EV_NACC];
 #pragma unroll
   for (int i = 0; i < EV_NACC; ++i) acc[i] = 0.f;
   const float lgK = lgamma_f((float)K);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NV; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / s.V, v = i % s.V;
+  // grid = (blocks per sample, N): no 64-bit division per voxel
+  const int64_t n = blockIdx.y;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < s.V; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = n * s.V + v;
     float zz[EV_MAXK], e[EV_MAXK], al[EV_MAXK], ed[EV_MAXK];
     load_voxel<T, KT>(in, ev_in, s, p, n, v, zz, e, al, ed);
     float S = 0.f;
@@ -293,12 +294,13 @@ k_crit_fwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int i = 0; i < EV_NACC; ++i) {
-    const double w = wave_sum((double)acc[i]);
+    const bool used = i == 0 || (i - 1) % EV_MAXK < K;       // accumulators of classes >= K stay zero
+    const double w = used ? wave_sum((double)acc[i]) : 0.0;
     if (lane == 0) red[wave][i] = w;
   }
   __syncthreads();
   if (threadIdx.x < EV_NACC)
-    partial[(int64_t)blockIdx.x * EV_NACC + threadIdx.x] =
+    partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * EV_NACC + threadIdx.x] =
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
@@ -395,8 +397,10 @@ k_crit_bwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
       c1[k] = (float)(w * (t.gTP * 1e-8 + t.gFP * (double)(1.f - 1e-8f) - t.gFN * 1e-8));
     }
   }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NV; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / s.V, v = i % s.V;
+  // grid = (blocks per sample, N): no 64-bit division per voxel
+  const int64_t n = blockIdx.y;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < s.V; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = n * s.V + v;
     float zz[EV_MAXK], e[EV_MAXK], al[EV_MAXK], ed[EV_MAXK];
     load_voxel<T, KT>(in, ev_in, s, p, n, v, zz, e, al, ed);
     float S = 0.f;
@@ -567,6 +571,15 @@ k_softplus_bwd(const float* __restrict__ z, const float* __restrict__ g, float* 
     dz[i] = g[i] * dsoftplus_f(z[i]);
 }
 
+// (blocks per sample, N) with at most EV_BLOCKS blocks in all (N <= EV_BLOCKS), else one block per sample
+static inline dim3 ev_grid2(int64_t N, int64_t V) {
+  int64_t bx = cdiv(V, 256 * 4);                       // >= 4 voxels per thread: amortises the final reduction
+  const int64_t cap = N < EV_BLOCKS ? EV_BLOCKS / N : 1;
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  return dim3((unsigned)bx, (unsigned)N);
+}
+
 static inline unsigned ev_grid(int64_t NV) {
   const int64_t b = cdiv(NV, 256);
   return (unsigned)(b < 1 ? 1 : (b > EV_BLOCKS ? EV_BLOCKS : b));
@@ -579,13 +592,13 @@ using namespace devis;
 extern "C" {
 
 size_t devis_evid_workspace_bytes(int64_t N, int64_t V, int64_t K) {
-  (void)N; (void)V; (void)K;
-  return (size_t)EV_BLOCKS * EV_NACC * sizeof(double);
+  (void)V; (void)K;
+  return (size_t)(N > EV_BLOCKS ? N : EV_BLOCKS) * EV_NACC * sizeof(double);
 }
 
 static bool crit_args_ok(const devis_evid_params* p, const void* in, const void* labels, int label_dtype, int64_t N,
                          int64_t V, int64_t K) {
-  if (!p || !in || N <= 0 || V <= 0 || K < 2 || K > EV_MAXK) return false;
+  if (!p || !in || N <= 0 || N > 65535 || V <= 0 || K < 2 || K > EV_MAXK) return false;
   if (p->kind < 0 || p->kind > CRIT_KL || (p->input_kind != 0 && p->input_kind != 1)) return false;
   if (p->kind != CRIT_KL && (!labels || label_dtype < 0 || label_dtype > 2)) return false;
   return true;
@@ -619,9 +632,11 @@ int devis_evid_crit_fwd(const devis_evid_params* p, const void* in, int64_t sN, 
   hipStream_t s = (hipStream_t)stream;
   const EvidShape sh = {sN, sV, sK, N, V, (int)K, evid_vec(in, sN, sV, sK, K, dtype)};
   const EvidParams ep = {p->input_kind, p->disentangle, p->lambda, p->a_au, p->eps};
-  const unsigned blocks = ev_grid(N * V);
+  if (N > 65535) return DEVIS_ERR_UNSUPPORTED;
+  const dim3 grid2 = ev_grid2(N, V);
+  const unsigned blocks = grid2.x * grid2.y;
   double* part = scal ? (double*)ws : nullptr;
-  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, DEVIS_DISPATCH_KT(K, hipLaunchKernelGGL((k_crit_fwd<T, KIND, KT>), dim3(blocks), dim3(256), 0, s, (const T*)in, sh, evidence_in, labels, label_dtype, ep, evidence_out, per_voxel_out, part))));
+  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, DEVIS_DISPATCH_KT(K, hipLaunchKernelGGL((k_crit_fwd<T, KIND, KT>), grid2, dim3(256), 0, s, (const T*)in, sh, evidence_in, labels, label_dtype, ep, evidence_out, per_voxel_out, part))));
   int rc = launch_status();
   if (rc || !scal) return rc;
   hipLaunchKernelGGL(k_evid_finalize, dim3(1), dim3(1024), 0, s, (const double*)ws, (int)blocks, (int)K, (double)(N * V), p->kind, p->a_au, scal);
@@ -640,7 +655,7 @@ int devis_evid_crit_bwd(const devis_evid_params* p, const void* in, int64_t sN, 
   if (evidence_in && (!p->input_kind || !has_dice)) return DEVIS_ERR_BAD_ARG;
   const EvidShape sh = {sN, sV, sK, N, V, (int)K, evid_vec(in, sN, sV, sK, K, dtype) && evid_vec(d_in, sN, sV, sK, K, dtype)};
   const EvidParams ep = {p->input_kind, p->disentangle, p->lambda, p->a_au, p->eps};
-  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, DEVIS_DISPATCH_KT(K, hipLaunchKernelGGL((k_crit_bwd<T, KIND, KT>), dim3(ev_grid(N * V)), dim3(256), 0, (hipStream_t)stream, (const T*)in, sh, evidence_in, labels, label_dtype, ep, scal, grad_loss, grad_pv, grad_dice, grad_ev, (T*)d_in, d_evidence_in))));
+  DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, DEVIS_DISPATCH_KT(K, hipLaunchKernelGGL((k_crit_bwd<T, KIND, KT>), ev_grid2(N, V), dim3(256), 0, (hipStream_t)stream, (const T*)in, sh, evidence_in, labels, label_dtype, ep, scal, grad_loss, grad_pv, grad_dice, grad_ev, (T*)d_in, d_evidence_in))));
   return launch_status();
 }
 

@@ -243,8 +243,9 @@ def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, r
 
 
 def conv_wgrad(x1: Tensor, x2: Optional[Tensor], dy: Tensor, geom: ConvGeom, wshape,
-               scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, want_bias: bool = True):
-    """-> (dw in the PyTorch layout `wshape` fp32, dbias fp32|None)."""
+               scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, want_bias: bool = True, out=None):
+    """-> (dw in the PyTorch layout `wshape` fp32, dbias fp32|None).  `out` = (dw, dbias) buffers to fill
+    (views of a flat gradient bucket) instead of fresh tensors."""
     _need_cuda(x1, x2, dy, scale, shift)
     c1 = x1.shape[-1]
     c2 = 0 if x2 is None else x2.shape[-1]
@@ -252,10 +253,11 @@ def conv_wgrad(x1: Tensor, x2: Optional[Tensor], dy: Tensor, geom: ConvGeom, wsh
     d = geom.desc(x1.shape[0], _spatial(x1), c1, c2, cout, x1.dtype)
     if _spatial(dy) != (d.OD, d.OH, d.OW):
         raise _lib.DevisError("wgrad: dy shape inconsistent with the layer")
-    dw = torch.empty(tuple(wshape), dtype=torch.float32, device=x1.device)
-    if dw.numel() != cout * (c1 + c2) * geom.k[0] * geom.k[1] * geom.k[2]:
+    dw, db = out if out is not None else (torch.empty(tuple(wshape), dtype=torch.float32, device=x1.device),
+                                          torch.empty((cout,), dtype=torch.float32, device=x1.device) if want_bias else None)
+    if dw.numel() != cout * (c1 + c2) * geom.k[0] * geom.k[1] * geom.k[2] or tuple(dw.shape) != tuple(wshape):
         raise _lib.DevisError("wgrad: weight shape mismatch")
-    db = torch.empty((cout,), dtype=torch.float32, device=x1.device) if want_bias else None
+    _check_out(dw, db)
     lib = _lib.load()
     nb = lib.devis_conv_wgrad_workspace_bytes(C.byref(d))
     ws = workspace(nb, x1.device) if nb else None
@@ -297,12 +299,21 @@ def convT_dgrad(dy: Tensor, wp: Tensor, k, x_shape, wt: Optional[Tensor] = None)
     return dx
 
 
-def convT_wgrad(x: Tensor, dy: Tensor, k, wshape):
+def _check_out(*ts) -> None:
+    for t in ts:
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda):
+            raise _lib.DevisError("gradient output buffers must be contiguous fp32 device tensors")
+
+
+def convT_wgrad(x: Tensor, dy: Tensor, k, wshape, out=None):
     _need_cuda(x, dy)
     cin, cout = wshape[0], wshape[1]
     d = _tdesc(x.shape, cin, cout, k, x.dtype)
-    dw = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
-    db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    dw, db = out if out is not None else (torch.empty(tuple(wshape), dtype=torch.float32, device=x.device),
+                                          torch.empty((cout,), dtype=torch.float32, device=x.device))
+    if tuple(dw.shape) != tuple(wshape) or db.numel() != cout:
+        raise _lib.DevisError("convT wgrad: output shape mismatch")
+    _check_out(dw, db)
     lib = _lib.load()
     nb = lib.devis_convT_wgrad_workspace_bytes(C.byref(d))
     ws = workspace(nb, x.device) if nb else None
@@ -368,14 +379,15 @@ def affine_act(x: Tensor, scale: Tensor, shift: Tensor, residual: Optional[Tenso
 
 
 def norm_relu_bwd(dy: Tensor, x: Tensor, scale: Tensor, shift: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
-                  groups: int, bn: bool, extra: Optional[Tensor] = None):
-    """Backward of relu(norm(x)) -> (dx (+extra), dgamma, dbeta)."""
+                  groups: int, bn: bool, extra: Optional[Tensor] = None, out=None):
+    """Backward of relu(norm(x)) -> (dx (+extra), dgamma, dbeta).  `out` = (dgamma, dbeta) buffers to fill."""
     _need_cuda(dy, x, extra)
     n, v, c = _nvc(x)
     mom = _moments(x, dy, scale, shift)
     f = dict(dtype=torch.float32, device=x.device)
     coef = torch.empty((3, n, c), **f)
-    dgamma, dbeta = torch.empty((c,), **f), torch.empty((c,), **f)
+    dgamma, dbeta = out if out is not None else (torch.empty((c,), **f), torch.empty((c,), **f))
+    _check_out(dgamma, dbeta)
     lib = _lib.load()
     check(lib.devis_norm_bwd_finalize(_p(mom), n, v, c, groups, int(bn), _p(gamma), _p(mean), _p(rstd),
                                       _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(dgamma), _p(dbeta), _stream()),

@@ -13,11 +13,59 @@ import torch
 import torch.distributed as dist
 
 
+class FlatGradSync:
+    """Bucketed all-reduce overlapped with backward, for a backbone that writes its gradients into one flat
+    buffer (devis_amd.unet3d.Unet).  The backbone calls ``begin(flat, bounds)`` at the start of its backward and
+    ``bucket_ready(i)`` as soon as every gradient in ``flat[bounds[i][0]:bounds[i][1]]`` is final; the slice is
+    all-reduced at once (RCCL runs it on its own stream, behind the kernels already queued) while the rest of
+    backward keeps the compute stream busy.  ``finish()`` joins the streams and turns sums into means.
+    The parameters' ``.grad`` are views of ``flat``, so there is no gather and no copy-back."""
+
+    def __init__(self, world: int, group=None):
+        self.world, self.group = world, group
+        self.flat, self.bounds, self.works = None, None, []
+        try:
+            self._avg = dist.get_backend(group) == "nccl"      # RCCL averages in the collective; gloo cannot
+        except Exception:
+            self._avg = False
+
+    def begin(self, flat: torch.Tensor, bounds) -> None:
+        self.flat, self.bounds, self.works = flat, list(bounds), []
+
+    def bucket_ready(self, i: int) -> None:
+        lo, hi = self.bounds[i]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self.works.append(dist.all_reduce(self.flat[lo:hi], op=op, group=self.group, async_op=True))
+
+    def finish(self) -> bool:
+        """-> True if a flat buffer was reduced since the last call."""
+        if self.flat is None:
+            return False
+        for w in self.works:
+            w.wait()
+        if not self._avg:
+            self.flat.div_(self.world)
+        self.flat, self.works = None, []
+        return True
+
+
 class GradientAllReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, group=None):
+    """Averages gradients across ranks.  With ``module`` (a TMSU or Unet whose backbone keeps a flat gradient
+    buffer) the all-reduce is bucketed and overlapped with backward (FlatGradSync); parameters outside such a
+    backbone, and any other model, go through flat buckets built after backward."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, group=None, module=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.flat_sync = None
+        backbone = getattr(module, "backbone", module)
+        if self.world > 1 and backbone is not None and hasattr(backbone, "_grad_sync"):
+            self.flat_sync = FlatGradSync(self.world, group)
+            backbone._grad_sync = self.flat_sync
+            self._backbone = backbone
+            own = {id(p) for p in backbone.parameters()}
+            self.params = [p for p in self.params if id(p) not in own]
         # reverse order: decoder/head gradients are produced first in backward
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
@@ -35,6 +83,15 @@ class GradientAllReducer:
         """Average .grad across ranks (async launch per bucket, then copy back)."""
         if self.world == 1:
             return
+        if self.flat_sync is not None:
+            flat = self._backbone.last_flat_grad
+            if self.flat_sync.finish() and flat is not None:
+                # autograd normally adopts the views as .grad; if it cloned one, refresh the copy
+                lo_ptr, hi_ptr = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+                for n, p in self._backbone.named_parameters():
+                    if p.grad is not None and not (lo_ptr <= p.grad.data_ptr() < hi_ptr):
+                        o, k, shape = self._backbone._grad_layout[n]
+                        p.grad.copy_(flat[o:o + k].view(shape))
         works = []
         for i, bucket in enumerate(self.buckets):
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]

@@ -74,6 +74,8 @@ class _Run:
                  packed: Dict[str, list]):
         self.P, self.B = params, buffers
         self.W = packed                       # name.weight -> [w_packed, w_dgrad | None] (ops.WeightPacker)
+        self.G: Dict[str, Tensor] = {}        # name -> fp32 view of the flat gradient buffer (set by backward)
+        self.sync = None                      # parallel.FlatGradSync or None
         self.dtype, self.training, self.taping = dtype, training, tape
         self.tape: List = []
         self.grads: Dict[str, Tensor] = {}
@@ -154,52 +156,58 @@ class _Run:
         return self.conv("endconv", h, G1)
 
     # ---- backward blocks
+    def _o(self, name, a=".weight", b=".bias"):
+        """(buffer for name+a, buffer for name+b): where the kernels write that layer's gradients"""
+        return (self.G[name + a], self.G[name + b])
+
     def _conv_bwd(self, e, dy, need_dx=True, skip=None):
         _, name, x, wp, geom = e
         g = self.grads
-        g[name + ".weight"], g[name + ".bias"] = ops.conv_wgrad(x, None, dy, geom, self.P[name + ".weight"].shape)
+        g[name + ".weight"], g[name + ".bias"] = ops.conv_wgrad(x, None, dy, geom, self.P[name + ".weight"].shape,
+                                                                out=self._o(name))
         return ops.conv_dgrad(dy, wp, geom, x.shape, residual=skip, wd=self._wd(name))[0] if need_dx else None
 
     def _en_bwd(self, e, dout):
         _, name, x, h, st1, st2, w1, w2 = e
         g, P = self.grads, self.P
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
-            h, None, dout, G3, P[name + ".conv2.weight"].shape, st2[0], st2[1])
+            h, None, dout, G3, P[name + ".conv2.weight"].shape, st2[0], st2[1], out=self._o(name + ".conv2"))
         da = ops.conv_dgrad(dout, w2, G3, h.shape, wd=self._wd(name + ".conv2"))[0]
         dh, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
-            da, h, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 8, False)
+            da, h, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 8, False, out=self._o(name + ".bn2"))
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
-            x, None, dh, G3, P[name + ".conv1.weight"].shape, st1[0], st1[1])
+            x, None, dh, G3, P[name + ".conv1.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv1"))
         da = ops.conv_dgrad(dh, w1, G3, x.shape, wd=self._wd(name + ".conv1"))[0]
         dx, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
-            da, x, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 8, False, extra=dout)
+            da, x, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 8, False, extra=dout,
+            out=self._o(name + ".bn1"))
         return dx
 
     def _de_bwd(self, e, dout):
         _, name, x, h1, h2, st1, st2, w1, w2 = e
         g, P = self.grads, self.P
         dh2, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
-            dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, True)
+            dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, True, out=self._o(name + ".bn2"))
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
-            h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1])
+            h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv2"))
         da = ops.conv_dgrad(dh2, w2, G3, h1.shape, wd=self._wd(name + ".conv2"))[0]
         dh1, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
-            da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, True)
+            da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, True, out=self._o(name + ".bn1"))
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
-            x, None, dh1, G3, P[name + ".conv1.weight"].shape)
+            x, None, dh1, G3, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
         return ops.conv_dgrad(dh1, w1, G3, x.shape, residual=dout, wd=self._wd(name + ".conv1"))[0]
 
     def _up_bwd(self, e, dy):
         _, name, x, prev, t, up, w1, wt, w3 = e
         g, P = self.grads, self.P
         g[name + ".conv3.weight"], g[name + ".conv3.bias"] = ops.conv_wgrad(
-            prev, up, dy, G1, P[name + ".conv3.weight"].shape)
+            prev, up, dy, G1, P[name + ".conv3.weight"].shape, out=self._o(name + ".conv3"))
         dprev, dup = ops.conv_dgrad(dy, w3, G1, prev.shape, up.shape[-1], wd=self._wd(name + ".conv3"))
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.convT_wgrad(
-            t, dup, (2, 2, 2), P[name + ".conv2.weight"].shape)
+            t, dup, (2, 2, 2), P[name + ".conv2.weight"].shape, out=self._o(name + ".conv2"))
         dt = ops.convT_dgrad(dup, wt, (2, 2, 2), t.shape, wt=self._wd(name + ".conv2"))
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
-            x, None, dt, G1, P[name + ".conv1.weight"].shape)
+            x, None, dt, G1, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
         dx = ops.conv_dgrad(dt, w1, G1, x.shape, wd=self._wd(name + ".conv1"))[0]
         return dx, dprev
 
@@ -211,15 +219,23 @@ class _Run:
         d = self._de_bwd(pop(), d); d, ds1 = self._up_bwd(pop(), d)   # DeBlock2, DeUpCat2
         d = self._de_bwd(pop(), d); d, ds2 = self._up_bwd(pop(), d)   # DeBlock3, DeUpCat3
         d = self._de_bwd(pop(), d); d, ds3 = self._up_bwd(pop(), d)   # DeBlock4, DeUpCat4
+        self._bucket_done(0)                                     # every decoder gradient is final
         for _ in range(4):
             d = self._en_bwd(pop(), d)                           # EnBlock4_4..1
+        self._bucket_done(1)                                     # the 128-channel stage (74 % of the parameters)
         d = self._conv_bwd(pop(), d, skip=ds3)               # EnDown3 (+ skip gradient)
         d = self._en_bwd(pop(), d); d = self._en_bwd(pop(), d)
         d = self._conv_bwd(pop(), d, skip=ds2)               # EnDown2
         d = self._en_bwd(pop(), d); d = self._en_bwd(pop(), d)
         d = self._conv_bwd(pop(), d, skip=ds1)               # EnDown1
         d = self._en_bwd(pop(), d)                               # EnBlock1
-        return self._conv_bwd(pop(), d, need_dx)                 # InitConv
+        d = self._conv_bwd(pop(), d, need_dx)                    # InitConv
+        self._bucket_done(2)
+        return d
+
+    def _bucket_done(self, i):
+        if self.sync is not None:
+            self.sync.bucket_ready(i)
 
 
 class _Unet3dFn(torch.autograd.Function):
@@ -232,7 +248,7 @@ class _Unet3dFn(torch.autograd.Function):
         taping = any(ctx.needs_input_grad)
         run = _Run(P, dict(model.named_buffers()), model.compute_dtype, model.training, taping, model._packed(P))
         logits = run.forward(ops.to_channels_last(x, model.compute_dtype))
-        ctx.run, ctx.names = run, names
+        ctx.run, ctx.names, ctx.model = run, names, model
         ctx.need_dx = ctx.needs_input_grad[1]
         return logits
 
@@ -241,9 +257,15 @@ class _Unet3dFn(torch.autograd.Function):
         run = ctx.run
         if not run.taping or not run.tape:
             raise RuntimeError("devis_amd Unet: backward called twice or without a taped forward")
+        model = ctx.model
+        flat, run.G = model._grad_views(dlogits.device)
+        run.sync = model._grad_sync
+        if run.sync is not None:
+            run.sync.begin(flat, model._bucket_bounds)
         dx_cl = run.backward(dlogits.contiguous(), ctx.need_dx)
         dx = ops.from_channels_last(dx_cl) if dx_cl is not None else None
-        grads = tuple(run.grads.get(n) for n in ctx.names)
+        grads = tuple(run.G[n] for n in ctx.names)
+        run.G = {}
         run.tape, run.grads = [], {}
         return (None, dx) + grads
 
@@ -296,6 +318,30 @@ class Unet(nn.Module):
         self._conv_modules = [(n + ".weight", m) for n, m in self.named_modules()
                               if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d))]
         self._packer = None
+        # gradient layout: reverse registration order = the order backward completes the modules
+        off, layout, bounds = 0, {}, []
+        plist = list(self.named_parameters())
+        for n, p_ in reversed(plist):
+            if n.startswith("EnBlock4_4.") and len(bounds) == 0:
+                bounds.append(off)                   # end of bucket 0: endconv ... DeUpCat4
+            if n.startswith("EnDown3.") and len(bounds) == 1:
+                bounds.append(off)                   # end of bucket 1: EnBlock4_*
+            layout[n] = (off, p_.numel(), tuple(p_.shape))
+            off += p_.numel()
+        self._grad_layout, self._grad_total = layout, off
+        self._bucket_bounds = [(0, bounds[0]), (bounds[0], bounds[1]), (bounds[1], off)]
+        self._grad_sync = None                       # parallel.FlatGradSync installs itself here
+        self.last_flat_grad = None
+
+    def _grad_views(self, device):
+        """One flat fp32 buffer per backward holding every parameter gradient, laid out in the order backward
+        produces them (decoder first), plus {name: view}.  The kernels write into the views, autograd hands
+        them out as .grad, and the data-parallel reducer all-reduces slices of the flat buffer in place -
+        no gather, no copy-back.  `_bucket_bounds` = element ranges of the three overlap buckets."""
+        flat = torch.empty((self._grad_total,), dtype=torch.float32, device=device)
+        views = {n: flat[o:o + k].view(shape) for n, (o, k, shape) in self._grad_layout.items()}
+        self.last_flat_grad = flat
+        return flat, views
 
     def _packed(self, P: Dict[str, Tensor]):
         """All conv weights in the kernels' layouts, one launch (rebuilt tables only if a parameter moved)."""

@@ -20,6 +20,17 @@ def _worker(rank, world, port, q):
     net[1].bias.grad = None                               # a parameter without gradient must still line up
     GradientAllReducer(net.parameters(), bucket_bytes=64).all_reduce()
     g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    # overlapped path: a backbone-style flat gradient buffer reduced bucket by bucket as backward "produces" it
+    from devis_amd.parallel import FlatGradSync
+    sync = FlatGradSync(world)
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    view = flat[3:7]                                      # a parameter's .grad is a view of the flat buffer
+    sync.begin(flat, [(0, 3), (3, 7), (7, 10)])
+    for i in range(3):
+        sync.bucket_ready(i)
+    assert sync.finish() and not sync.finish()
+    assert torch.allclose(flat, torch.arange(10, dtype=torch.float32) * 1.5)
+    assert torch.allclose(view, torch.arange(3, 7, dtype=torch.float32) * 1.5)
     q.put((rank, w0, g))
     dist.barrier()
     dist.destroy_process_group()

@@ -124,3 +124,27 @@ def test_shape_errors():
         net(torch.zeros(1, 4, 12, 16, 16).cuda())
     with pytest.raises(ValueError):
         net(torch.zeros(1, 3, 16, 16, 16).cuda())
+
+
+def test_gradients_are_views_of_one_flat_buffer():
+    """Every .grad the backbone hands to autograd is a view of its flat gradient buffer (what the overlapped
+    all-reduce reduces in place), laid out decoder-first in three buckets."""
+    from devis_amd import TMSU
+    torch.manual_seed(3)
+    m = TMSU(brats_args(compute_dtype=torch.bfloat16))
+    m.train()
+    x, y = _inputs(3, (1, 4, 16, 16, 16))
+    _, loss = m(x.cuda(), y.cuda(), 25, 'train', 'BraTS')
+    loss.backward()
+    bb = m.backbone
+    flat = bb.last_flat_grad
+    assert flat is not None and flat.numel() == sum(p.numel() for p in bb.parameters())
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    for n, p in bb.named_parameters():
+        o, k, shape = bb._grad_layout[n]
+        assert p.grad is not None and p.grad.data_ptr() == lo + 4 * o, n
+        assert torch.equal(p.grad, flat[o:o + k].view(shape))
+    b = bb._bucket_bounds
+    assert b[0][0] == 0 and b[0][1] == b[1][0] and b[1][1] == b[2][0] and b[2][1] == flat.numel()
+    assert bb._grad_layout["endconv.bias"][0] < b[0][1] <= bb._grad_layout["EnBlock4_4.conv2.weight"][0] < b[1][1]
+    assert bb._grad_layout["InitConv.conv.weight"][0] >= b[1][1]
