@@ -45,6 +45,14 @@ def _need_cuda(*ts: Optional[Tensor]) -> None:
                 raise _lib.DevisError("devis_amd kernels need contiguous tensors")
 
 
+def require_device(*ts: Optional[Tensor]) -> None:
+    """Model-level guard: inputs and parameters must be on the GPU (no CPU path exists)."""
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DevisError("devis_amd kernels need GPU tensors (got a %s tensor); "
+                                  "there is no CPU fallback" % t.device)
+
+
 def _spatial(x: Tensor) -> Tuple[int, int, int]:
     if x.dim() == 5:
         return x.shape[1], x.shape[2], x.shape[3]

@@ -357,6 +357,7 @@ class Unet(nn.Module):
             raise ValueError("Unet expects (N, %d, D, H, W), got %s" % (self.InitConv.conv.in_channels, tuple(x.shape)))
         if any(s % 8 for s in x.shape[2:]):
             raise ValueError("Unet needs D, H, W divisible by 8 (three stride-2 stages), got %s" % (tuple(x.shape[2:]),))
+        ops.require_device(x, self.InitConv.conv.weight)
         return _Unet3dFn.apply(self, x, *[p for _, p in self.named_parameters()])
 
     def forward(self, x: Tensor) -> Tensor:
