@@ -131,6 +131,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     from devis_amd import TMSU
     from devis_amd.parallel import GradientAllReducer
+    from devis_amd.optim import FusedAdam
     from devis_amd.train import adjust_learning_rate
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -138,7 +139,7 @@ def main():
     torch.manual_seed(0)                       # identical replicas on every rank
     model = TMSU(args)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=1e-5)     # trainUMIS.py:1394
+    opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=1e-5, module=model)   # trainUMIS.py:1394, one launch
     reducer = GradientAllReducer(model.parameters(), module=model) if world > 1 else None
     g = torch.Generator().manual_seed(1234 + rank)
     S = a.size

@@ -40,6 +40,11 @@ class ConvTDesc(C.Structure):
                 ("KD", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("dtype", C.c_int32)]
 
 
+class ConvStats(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("reserved", C.c_int32), ("partials", C.c_void_p), ("partials_bytes", C.c_size_t),
+                ("chunks", C.c_int64), ("x_ref", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p)]
+
+
 class EvidParams(C.Structure):
     _fields_ = [("kind", C.c_int), ("input_kind", C.c_int), ("disentangle", C.c_int),
                 ("lam", C.c_float), ("a_au", C.c_float), ("eps", C.c_float)]
@@ -51,6 +56,7 @@ PACK_CHUNK = 1024
 
 _P, _I64, _I, _F, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _CD, _CTD, _EP = C.POINTER(ConvDesc), C.POINTER(ConvTDesc), C.POINTER(EvidParams)
+_CS = C.POINTER(ConvStats)
 
 # name -> (restype, argtypes); every symbol include/devis_hip.h declares
 SIGNATURES = {
@@ -64,6 +70,9 @@ SIGNATURES = {
     "devis_pack_weights_batch": (_I, [_P, _P, _I64, _I, _P]),
     "devis_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devis_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P]),
+    "devis_conv_stats_chunks": (_I64, [_CD, _I, _I, _I, _I]),
+    "devis_conv_fwd_stats": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _CS, _P]),
+    "devis_conv_dgrad_stats": (_I, [_CD, _P, _P, _P, _P, _P, _P, _CS, _P]),
     "devis_repack_conv_weight_dgrad": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
     "devis_conv_wgrad_workspace_bytes": (_SZ, [_CD]),
     "devis_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -78,6 +87,11 @@ SIGNATURES = {
     "devis_affine_act": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P]),
     "devis_norm_bwd_moments": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
     "devis_norm_bwd_finalize": (_I, [_P, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "devis_channel_moments_partials": (_I, [_P, _I64, _I64, _I64, _I, _P, _SZ, C.POINTER(C.c_int64), _P]),
+    "devis_norm_bwd_moments_partials": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _SZ, C.POINTER(C.c_int64), _P]),
+    "devis_gn_finalize_partials": (_I, [_P, _I64, _I64, _I64, _I64, _I64, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "devis_bn_finalize_partials": (_I, [_P, _I64, _I64, _I64, _I64, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "devis_norm_bwd_finalize_partials": (_I, [_P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devis_norm_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P]),
     "devis_add": (_I, [_P, _P, _P, _I64, _I, _P]),
     "devis_maxpool2d_fwd": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),
@@ -88,6 +102,7 @@ SIGNATURES = {
     "devis_evid_crit_fwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     "devis_evid_crit_bwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devis_evid_infer": (_I, [_P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "devis_adam_step": (_I, [_P, _P, _P, _P, _I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _P]),
     "devis_softplus_bwd": (_I, [_P, _P, _P, _I64, _P]),
 }
 

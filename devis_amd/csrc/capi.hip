@@ -1,6 +1,7 @@
 // C-ABI entry points for convolution: validate, then route to the MFMA implicit-GEMM
 // kernels (conv_mfma.hip) when they take the shape, else to the direct kernels.
 #include "common.h"
+#include "mfma_common.h"
 
 namespace devis {
 // conv_direct.hip
@@ -11,8 +12,9 @@ int conv_wgrad_direct(const devis_conv_desc*, const void*, const void*, const fl
                       float*, float*, hipStream_t);
 // conv_mfma.hip: return DEVIS_ERR_UNSUPPORTED when the shape is not theirs
 int conv_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
-                  const float*, const void*, void*, hipStream_t);
-int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, hipStream_t);
+                  const float*, const void*, void*, const StatsArgs*, int64_t*, hipStream_t);
+int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, const StatsArgs*,
+                    int64_t*, hipStream_t);
 // pointwise_mfma.hip
 int conv1_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const void*, void*, hipStream_t);
 int conv1_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, hipStream_t);
@@ -41,14 +43,50 @@ using namespace devis;
 
 extern "C" {
 
-int devis_conv_fwd(const devis_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
-                   const float* in_scale, const float* in_shift, const void* residual, void* y, void* stream) {
+// validated copy of the caller's statistics request (mode 0 when there is none)
+static int stats_args(const devis_conv_stats* st, int64_t C, int64_t N, StatsArgs* out) {
+  *out = StatsArgs{};
+  if (!st || st->mode == 0) return DEVIS_OK;
+  if (st->mode != 1 && st->mode != 2) return DEVIS_ERR_BAD_ARG;
+  if (!st->partials || st->chunks <= 0 || st->chunks > 0x7fffffff) return DEVIS_ERR_BAD_ARG;
+  if (st->mode == 2 && (!st->x_ref || !st->scale || !st->shift)) return DEVIS_ERR_BAD_ARG;
+  if (st->partials_bytes < (size_t)(N * st->chunks * C * 2) * sizeof(double)) return DEVIS_ERR_WORKSPACE;
+  out->mode = st->mode; out->chunks = (int)st->chunks; out->C = (int)C; out->partial = st->partials;
+  out->xref = (const bf16*)st->x_ref; out->sc = st->scale; out->sh = st->shift;
+  return DEVIS_OK;
+}
+
+int64_t devis_conv_stats_chunks(const devis_conv_desc* d, int dgrad, int mode, int has_prologue, int has_residual) {
+  if (!conv_desc_ok(d) || (mode != 1 && mode != 2)) return 0;
+  // placeholders: plan-only calls return before anything is dereferenced or launched
+  const void* ph = reinterpret_cast<const void*>((uintptr_t)256);
+  const float* phf = reinterpret_cast<const float*>((uintptr_t)256);
+  StatsArgs st = StatsArgs{};
+  st.mode = mode;
+  int64_t chunks = 0;
+  int rc;
+  if (dgrad) {
+    if (has_prologue) return 0;
+    rc = conv_dgrad_mfma(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph), nullptr, &st, &chunks, nullptr);
+  } else {
+    rc = conv_fwd_mfma(d, ph, nullptr, ph, phf, has_prologue ? phf : nullptr, has_prologue ? phf : nullptr,
+                       has_residual ? ph : nullptr, const_cast<void*>(ph), &st, &chunks, nullptr);
+  }
+  return rc == DEVIS_OK ? chunks : 0;
+}
+
+int devis_conv_fwd_stats(const devis_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                         const float* in_scale, const float* in_shift, const void* residual, void* y,
+                         const devis_conv_stats* stats, void* stream) {
   if (!conv_desc_ok(d) || !x1 || !w || !y) return DEVIS_ERR_BAD_ARG;
   if ((d->C2 > 0) != (x2 != nullptr)) return DEVIS_ERR_BAD_ARG;
   if ((in_scale != nullptr) != (in_shift != nullptr)) return DEVIS_ERR_BAD_ARG;
+  StatsArgs st;
+  int rc = stats_args(stats, d->Cout, d->N, &st);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  int rc = conv_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
-  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = conv_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, &st, nullptr, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;      // statistics only come from the MFMA kernels
   if (!in_scale) {
     rc = conv1_fwd_mfma(d, x1, x2, w, bias, residual, y, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
@@ -56,19 +94,32 @@ int devis_conv_fwd(const devis_conv_desc* d, const void* x1, const void* x2, con
   return conv_fwd_direct(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
 }
 
-int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, const void* w_dgrad,
-                     const void* residual, void* dx1, void* dx2, void* stream) {
+int devis_conv_fwd(const devis_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                   const float* in_scale, const float* in_shift, const void* residual, void* y, void* stream) {
+  return devis_conv_fwd_stats(d, x1, x2, w, bias, in_scale, in_shift, residual, y, nullptr, stream);
+}
+
+int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void* w, const void* w_dgrad,
+                           const void* residual, void* dx1, void* dx2, const devis_conv_stats* stats, void* stream) {
   if (!conv_desc_ok(d) || !dy || !w || !dx1) return DEVIS_ERR_BAD_ARG;
   if ((d->C2 > 0) != (dx2 != nullptr)) return DEVIS_ERR_BAD_ARG;
   if (residual && d->C2 > 0) return DEVIS_ERR_BAD_ARG;
+  StatsArgs st;
+  int rc = stats_args(stats, d->C1, d->N, &st);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  int rc = conv_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, s);
-  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = conv_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;
   rc = conv1_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = conv3s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   return conv_dgrad_direct(d, dy, w, residual, dx1, dx2, s);
+}
+
+int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, const void* w_dgrad,
+                     const void* residual, void* dx1, void* dx2, void* stream) {
+  return devis_conv_dgrad_stats(d, dy, w, w_dgrad, residual, dx1, dx2, nullptr, stream);
 }
 
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d) {

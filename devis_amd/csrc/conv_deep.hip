@@ -26,9 +26,10 @@ struct DeepArgs {
   bf16* y;
   int N, D, H, W, Cout;
   int ntd, nth, ntw;
+  StatsArgs st;       // norm statistics gathered in the epilogue (mode 0: off)
 };
 
-template <int CIN, int TD, int TH, bool PRO>
+template <int CIN, int TD, int TH, bool PRO, int STATS>
 __global__ void __launch_bounds__(256)
 k_conv3_deep(DeepArgs a) {
   constexpr int NCH = CIN / 32, MT = 2;
@@ -174,6 +175,19 @@ k_conv3_deep(DeepArgs a) {
   }
 
   // ---- epilogue: + bias (+ residual), 4 consecutive cout of one voxel per lane -> 8-byte stores
+  float f0[MT][4], f1[MT][4], scs[MT][4], shs[MT][4];
+  if (STATS) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f0[m][k] = 0.f; f1[m][k] = 0.f;
+        if (STATS == 2) {
+          scs[m][k] = a.st.sc[n * a.Cout + co_base + m * 16 + lq * 4 + k];
+          shs[m][k] = a.st.sh[n * a.Cout + co_base + m * 16 + lq * 4 + k];
+        }
+      }
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int g = wave * NT + j;
@@ -196,13 +210,35 @@ k_conv3_deep(DeepArgs a) {
       o.x = pack_bf2(v0, v1);
       o.y = pack_bf2(v2, v3);
       *reinterpret_cast<uint2*>(a.y + vox * a.Cout + co) = o;
+      if (STATS) {
+        uint2 xr = o;
+        if (STATS == 2) xr = *reinterpret_cast<const uint2*>(a.st.xref + vox * a.Cout + co);
+        stats_accum<STATS>(o, xr, scs[m], shs[m], f0[m], f1[m]);
+      }
     }
+  }
+  if (STATS) {
+    __syncthreads();               // every wave is done reading its LDS fragments
+    const int chunk = tile % (a.ntw * a.nth * a.ntd);
+    stats_finish<MT>(f0, f1, reinterpret_cast<double*>(smem),
+                     a.st.partial + (((size_t)n * a.st.chunks + chunk) * a.Cout + co_base) * 2);
   }
 }
 
+template <int CIN, int TD, int TH, bool PRO, int STATS>
+static int launch_deep_k(const DeepArgs& a, dim3 grid, int lds, hipStream_t s) {
+  auto k = k_conv3_deep<CIN, TD, TH, PRO, STATS>;
+  static bool attr_done = false;
+  if (!attr_done) { if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds))) return DEVIS_ERR_HIP; attr_done = true; }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  return launch_status();
+}
+
+// plan_chunks != null: only report the statistics chunks per sample this launch would leave
 template <int CIN, int TD, int TH>
 static int launch_deep(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
-                       const float* sh, const void* res, void* y, hipStream_t s) {
+                       const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks,
+                       hipStream_t s) {
   constexpr int HV = (TD + 2) * (TH + 2) * 18;
   constexpr int LDS = ((HV * 4 + 255) / 256) * 256 * 16 + 27 * 32 * 64;
   DeepArgs a;
@@ -211,28 +247,31 @@ static int launch_deep(const devis_conv_desc* d, const void* x, const void* w, c
   a.ntd = (int)cdiv(a.D, TD); a.nth = (int)cdiv(a.H, TH); a.ntw = (int)cdiv(a.W, 16);
   const int64_t tiles = (int64_t)a.N * a.ntd * a.nth * a.ntw;
   if (tiles > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)tiles, (unsigned)(d->Cout / 32));
-  static bool attr_done[2] = {false, false};
-  if (sc) {
-    auto k = k_conv3_deep<CIN, TD, TH, true>;
-    if (!attr_done[0]) { if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS))) return DEVIS_ERR_HIP; attr_done[0] = true; }
-    hipLaunchKernelGGL(k, grid, dim3(256), LDS, s, a);
-  } else {
-    auto k = k_conv3_deep<CIN, TD, TH, false>;
-    if (!attr_done[1]) { if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS))) return DEVIS_ERR_HIP; attr_done[1] = true; }
-    hipLaunchKernelGGL(k, grid, dim3(256), LDS, s, a);
+  if (plan_chunks) {
+    *plan_chunks = (st && st->mode == 2 && sc) ? 0 : (int64_t)a.ntd * a.nth * a.ntw;
+    return DEVIS_OK;
   }
-  return launch_status();
+  const dim3 grid((unsigned)tiles, (unsigned)(d->Cout / 32));
+  a.st = StatsArgs{};
+  const int mode = st ? st->mode : 0;
+  if (mode) {
+    a.st = *st;
+    if (a.st.chunks != a.ntd * a.nth * a.ntw || a.st.C != a.Cout) return DEVIS_ERR_BAD_ARG;
+    if (mode == 2 && sc) return DEVIS_ERR_UNSUPPORTED;
+  }
+  if (mode == 1) return sc ? launch_deep_k<CIN, TD, TH, true, 1>(a, grid, LDS, s) : launch_deep_k<CIN, TD, TH, false, 1>(a, grid, LDS, s);
+  if (mode == 2) return launch_deep_k<CIN, TD, TH, false, 2>(a, grid, LDS, s);
+  return sc ? launch_deep_k<CIN, TD, TH, true, 0>(a, grid, LDS, s) : launch_deep_k<CIN, TD, TH, false, 0>(a, grid, LDS, s);
 }
 
 // stride-1 3x3x3 with Cin == Cout in {64, 128}, bf16; anything else is unsupported
 int conv3_deep(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
-               const float* sh, const void* res, void* y, hipStream_t s) {
+               const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s) {
   if (d->dtype != DEVIS_BF16 || d->C2 != 0 || d->SD != 1 || d->C1 != d->Cout) return DEVIS_ERR_UNSUPPORTED;
   if (d->OD != d->ID || d->OH != d->IH || d->OW != d->IW) return DEVIS_ERR_UNSUPPORTED;
   if (d->N * d->ID * d->IH * d->IW * d->C1 >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
-  if (d->C1 == 128) return launch_deep<128, 2, 4>(d, x, w, bias, sc, sh, res, y, s);
-  if (d->C1 == 64) return launch_deep<64, 4, 4>(d, x, w, bias, sc, sh, res, y, s);
+  if (d->C1 == 128) return launch_deep<128, 2, 4>(d, x, w, bias, sc, sh, res, y, st, plan_chunks, s);
+  if (d->C1 == 64) return launch_deep<64, 4, 4>(d, x, w, bias, sc, sh, res, y, st, plan_chunks, s);
   return DEVIS_ERR_UNSUPPORTED;
 }
 

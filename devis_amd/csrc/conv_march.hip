@@ -32,10 +32,11 @@ struct MarchArgs {
   bf16* y;
   int N, D, H, W;
   int nth, ntw, ndc, DL;
+  StatsArgs st;       // norm statistics gathered in the epilogue (mode 0: off)
 };
 
 // FULL: H % TH == 0 and W % TW == 0 (no partial tiles -> unconditional stores)
-template <int TH, int TW, bool PRO, bool RES, bool CIN4, bool FULL>
+template <int TH, int TW, bool PRO, bool RES, bool CIN4, bool FULL, int STATS>
 __global__ void __launch_bounds__(256)
 k_conv3_c16_march(MarchArgs a) {
   constexpr int HH = TH + 2, HW = TW + 2, HP = HH * HW;
@@ -162,6 +163,14 @@ k_conv3_c16_march(MarchArgs a) {
     ooff[j] = oin[j] ? (unsigned)((oh * a.W + ow) * 16 + lq * 4) : 0u;
   }
 
+  // epilogue statistics: fp32 running sums of this lane's 4 channels (<= DL * NT addends), see mfma_common.h
+  float f0[1][4] = {{0.f, 0.f, 0.f, 0.f}}, f1[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+  float scs[4] = {0.f, 0.f, 0.f, 0.f}, shs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (STATS == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { scs[j] = a.st.sc[n * 16 + lq * 4 + j]; shs[j] = a.st.sh[n * 16 + lq * 4 + j]; }
+  }
+
   const int np = d1 - d0;
   for (int it = 0; it < np; ++it) {
     const int od = d0 + it;
@@ -173,6 +182,12 @@ k_conv3_c16_march(MarchArgs a) {
       const bf16* rp = a.res + pbase;
 #pragma unroll
       for (int j = 0; j < NT; ++j) rv[j] = *reinterpret_cast<const uint2*>(rp + ooff[j]);
+    }
+    uint2 xv[NT];
+    if (STATS == 2) {
+      const bf16* xp = a.st.xref + pbase;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) xv[j] = *reinterpret_cast<const uint2*>(xp + ooff[j]);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -228,24 +243,50 @@ k_conv3_c16_march(MarchArgs a) {
       o.x = pack_bf2(v0, v1);
       o.y = pack_bf2(v2, v3);
       if (FULL || oin[j]) *reinterpret_cast<uint2*>(yp + ooff[j]) = o;
+      if (STATS && (FULL || oin[j])) stats_accum<STATS>(o, STATS == 2 ? xv[j] : o, scs, shs, f0[0], f1[0]);
     }
     __builtin_amdgcn_sched_barrier(0);
 
     store_plane(od + 2, (it + 3) & (R - 1), pre);
     __syncthreads();
   }
+  if (STATS) {
+    const int chunk = tile % (a.ntw * a.nth * a.ndc);
+    stats_finish<1>(f0, f1, reinterpret_cast<double*>(smem), a.st.partial + ((size_t)n * a.st.chunks + chunk) * 32);
+  }
 }
 
-template <int TH, int TW, bool PRO, bool RES, bool CIN4>
+template <int TH, int TW, bool PRO, bool RES, bool CIN4, int STATS>
 static void launch_march_v(bool full, dim3 grid, hipStream_t s, const MarchArgs& a) {
   constexpr int LDS = 4 * (((TH + 2) * (TW + 2) * 2 + 255) / 256) * 256 * 16;
-  if (full) hipLaunchKernelGGL((k_conv3_c16_march<TH, TW, PRO, RES, CIN4, true>), grid, dim3(256), LDS, s, a);
-  else hipLaunchKernelGGL((k_conv3_c16_march<TH, TW, PRO, RES, CIN4, false>), grid, dim3(256), LDS, s, a);
+  if (full) hipLaunchKernelGGL((k_conv3_c16_march<TH, TW, PRO, RES, CIN4, true, STATS>), grid, dim3(256), LDS, s, a);
+  else hipLaunchKernelGGL((k_conv3_c16_march<TH, TW, PRO, RES, CIN4, false, STATS>), grid, dim3(256), LDS, s, a);
 }
 
+template <int TH, int TW, int STATS>
+static int launch_march_s(const devis_conv_desc* d, bool full, dim3 grid, hipStream_t s, const MarchArgs& a) {
+  const bool sc = a.sc != nullptr, res = a.res != nullptr;
+  if (d->C1 == 4) {
+    if (sc || res || STATS == 2) return DEVIS_ERR_UNSUPPORTED;
+    launch_march_v<TH, TW, false, false, true, STATS == 2 ? 0 : STATS>(full, grid, s, a);
+  } else if (STATS == 2) {            // dgrad in front of a norm backward: no prologue, no residual
+    if (sc || res) return DEVIS_ERR_UNSUPPORTED;
+    launch_march_v<TH, TW, false, false, false, STATS>(full, grid, s, a);
+  } else if (sc) {
+    if (res) launch_march_v<TH, TW, true, true, false, STATS == 2 ? 0 : STATS>(full, grid, s, a);
+    else launch_march_v<TH, TW, true, false, false, STATS == 2 ? 0 : STATS>(full, grid, s, a);
+  } else {
+    if (res) launch_march_v<TH, TW, false, true, false, STATS == 2 ? 0 : STATS>(full, grid, s, a);
+    else launch_march_v<TH, TW, false, false, false, STATS == 2 ? 0 : STATS>(full, grid, s, a);
+  }
+  return launch_status();
+}
+
+// plan_chunks != null: only report the statistics chunks per sample this launch would leave
 template <int TH, int TW>
 static int launch_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
-                        const float* sh, const void* res, void* y, hipStream_t s) {
+                        const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks,
+                        hipStream_t s) {
   MarchArgs a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.sc = sc; a.sh = sh; a.res = (const bf16*)res; a.y = (bf16*)y;
   a.N = (int)d->N; a.D = (int)d->OD; a.H = (int)d->OH; a.W = (int)d->OW;
@@ -262,29 +303,31 @@ static int launch_march(const devis_conv_desc* d, const void* x, const void* w, 
   a.ndc = (int)cdiv(a.D, dl);
   const int64_t tiles = (int64_t)a.N * a.ndc * a.nth * a.ntw;
   if (tiles > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
+  if (plan_chunks) {
+    const bool can = !(st && st->mode == 2 && (sc || res || d->C1 == 4));
+    *plan_chunks = can ? (int64_t)a.ndc * a.nth * a.ntw : 0;
+    return DEVIS_OK;
+  }
   const dim3 grid((unsigned)tiles);
   const bool full = a.H % TH == 0 && a.W % TW == 0;
-  if (d->C1 == 4) {
-    if (sc || res) return DEVIS_ERR_UNSUPPORTED;
-    launch_march_v<TH, TW, false, false, true>(full, grid, s, a);
-  } else if (sc) {
-    if (res) launch_march_v<TH, TW, true, true, false>(full, grid, s, a);
-    else launch_march_v<TH, TW, true, false, false>(full, grid, s, a);
-  } else {
-    if (res) launch_march_v<TH, TW, false, true, false>(full, grid, s, a);
-    else launch_march_v<TH, TW, false, false, false>(full, grid, s, a);
+  a.st = StatsArgs{};
+  if (st && st->mode) {
+    a.st = *st;
+    if (a.st.chunks != a.ndc * a.nth * a.ntw || a.st.C != 16) return DEVIS_ERR_BAD_ARG;
+    if (a.st.mode == 1) return launch_march_s<TH, TW, 1>(d, full, grid, s, a);
+    return launch_march_s<TH, TW, 2>(d, full, grid, s, a);
   }
-  return launch_status();
+  return launch_march_s<TH, TW, 0>(d, full, grid, s, a);
 }
 
 // stride-1 3x3x3, Cout = 16, Cin = 16 (or 4: the first layer), bf16; anything else is unsupported
 int conv3_c16_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
-                    const float* sh, const void* res, void* y, hipStream_t s) {
+                    const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s) {
   if (d->dtype != DEVIS_BF16 || d->Cout != 16 || (d->C1 != 16 && d->C1 != 4) || d->C2 != 0 || d->SD != 1) return DEVIS_ERR_UNSUPPORTED;
   if (d->OD != d->ID || d->OH != d->IH || d->OW != d->IW) return DEVIS_ERR_UNSUPPORTED;
   if (d->IH * d->IW * 16 >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
-  if (d->OW <= 16) return launch_march<16, 16>(d, x, w, bias, sc, sh, res, y, s);
-  return launch_march<8, 32>(d, x, w, bias, sc, sh, res, y, s);
+  if (d->OW <= 16) return launch_march<16, 16>(d, x, w, bias, sc, sh, res, y, st, plan_chunks, s);
+  return launch_march<8, 32>(d, x, w, bias, sc, sh, res, y, st, plan_chunks, s);
 }
 
 }  // namespace devis

@@ -28,6 +28,7 @@ struct Conv3Args {
   int N, ID, IH, IW, OD, OH, OW, Cout;
   int ntd, nth, ntw;
   int cin_real;       // 4 for the first layer (zero-extended to 16 in LDS), else CIN
+  StatsArgs st;       // norm statistics gathered in the epilogue (mode 0: off)
 };
 
 template <int CIN, int COUT_T, int TD, int TH, int TW, int S>
@@ -51,7 +52,7 @@ __device__ __forceinline__ constexpr int tap_off(int t) {
   return ((t / 9) * HH + (t / 3) % 3) * HW + t % 3;
 }
 
-template <int CIN, int COUT_T, int TD, int TH, int TW, int S, bool PRO>
+template <int CIN, int COUT_T, int TD, int TH, int TW, int S, bool PRO, int STATS>
 __global__ void __launch_bounds__(256)
 k_conv3_mfma(Conv3Args a) {
   using C = Cfg<CIN, COUT_T, TD, TH, TW, S>;
@@ -188,6 +189,19 @@ k_conv3_mfma(Conv3Args a) {
   }
 
   // ---- epilogue: + bias (+ residual), 4 consecutive cout of one voxel per lane -> 8-byte stores
+  float f0[C::MT][4], f1[C::MT][4], scs[C::MT][4], shs[C::MT][4];
+  if (STATS) {
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f0[m][k] = 0.f; f1[m][k] = 0.f;
+        if (STATS == 2) {
+          scs[m][k] = a.st.sc[n * a.Cout + co_base + m * 16 + lq * 4 + k];
+          shs[m][k] = a.st.sh[n * a.Cout + co_base + m * 16 + lq * 4 + k];
+        }
+      }
+  }
 #pragma unroll
   for (int j = 0; j < C::NT; ++j) {
     const int g = wave * C::NT + j;
@@ -211,13 +225,39 @@ k_conv3_mfma(Conv3Args a) {
       o.x = pack_bf2(v0, v1);
       o.y = pack_bf2(v2, v3);
       *reinterpret_cast<uint2*>(a.y + vox * a.Cout + co) = o;
+      if (STATS) {
+        uint2 xr = o;
+        if (STATS == 2) xr = *reinterpret_cast<const uint2*>(a.st.xref + vox * a.Cout + co);
+        stats_accum<STATS>(o, xr, scs[m], shs[m], f0[m], f1[m]);
+      }
     }
+  }
+  if (STATS) {
+    __syncthreads();               // every wave is done reading its LDS fragments
+    const int chunk = tile % (a.ntw * a.nth * a.ntd);
+    stats_finish<C::MT>(f0, f1, reinterpret_cast<double*>(smem),
+                        a.st.partial + (((size_t)n * a.st.chunks + chunk) * a.Cout + co_base) * 2);
   }
 }
 
-template <int CIN, int COUT_T, int TD, int TH, int TW, int S>
+template <int CIN, int COUT_T, int TD, int TH, int TW, int S, bool PRO, int STATS>
+static int launch_conv3_k(const Conv3Args& a, dim3 grid, hipStream_t s) {
+  using C = Cfg<CIN, COUT_T, TD, TH, TW, S>;
+  auto k = k_conv3_mfma<CIN, COUT_T, TD, TH, TW, S, PRO, STATS>;
+  if (C::LDS_BYTES > 65536) {
+    static bool once = false;
+    if (!once) { if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES))) return DEVIS_ERR_HIP; once = true; }
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), C::LDS_BYTES, s, a);
+  return launch_status();
+}
+
+// ST: 0 = this shape never gathers statistics, 1 = forward moments (mode 1), 2 = mode 1 and, without a
+// prologue, the norm-backward moments (mode 2).  plan_chunks != null: only report the chunks per sample.
+template <int CIN, int COUT_T, int TD, int TH, int TW, int S, int ST = 0>
 static int launch_conv3(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
-                        const float* sh, const void* res, void* y, hipStream_t s) {
+                        const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks,
+                        hipStream_t s) {
   using C = Cfg<CIN, COUT_T, TD, TH, TW, S>;
   Conv3Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.sc = sc; a.sh = sh; a.res = (const bf16*)res; a.y = (bf16*)y;
@@ -227,30 +267,34 @@ static int launch_conv3(const devis_conv_desc* d, const void* x, const void* w, 
   a.ntd = (int)cdiv(d->OD, TD); a.nth = (int)cdiv(d->OH, TH); a.ntw = (int)cdiv(d->OW, TW);
   const int64_t tiles = (int64_t)a.N * a.ntd * a.nth * a.ntw;
   if (tiles > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)tiles, (unsigned)(d->Cout / COUT_T));
-  if (sc) {
-    auto k = k_conv3_mfma<CIN, COUT_T, TD, TH, TW, S, true>;
-    if (C::LDS_BYTES > 65536) {
-      static bool once = false;
-      if (!once) { if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES))) return DEVIS_ERR_HIP; once = true; }
-    }
-    hipLaunchKernelGGL(k, grid, dim3(256), C::LDS_BYTES, s, a);
-  } else {
-    auto k = k_conv3_mfma<CIN, COUT_T, TD, TH, TW, S, false>;
-    if (C::LDS_BYTES > 65536) {
-      static bool once = false;
-      if (!once) { if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES))) return DEVIS_ERR_HIP; once = true; }
-    }
-    hipLaunchKernelGGL(k, grid, dim3(256), C::LDS_BYTES, s, a);
+  if (plan_chunks) {
+    const bool can = ST >= 1 && !(st && st->mode == 2 && (ST < 2 || sc));
+    *plan_chunks = can ? (int64_t)a.ntd * a.nth * a.ntw : 0;
+    return DEVIS_OK;
   }
-  return launch_status();
+  const dim3 grid((unsigned)tiles, (unsigned)(d->Cout / COUT_T));
+  static_assert(C::LDS_BYTES >= 4 * C::MT * 32 * 8, "LDS too small for the statistics reduction");
+  a.st = StatsArgs{};
+  const int mode = st ? st->mode : 0;
+  if (mode) {
+    if (ST == 0 || (mode == 2 && (ST < 2 || sc))) return DEVIS_ERR_UNSUPPORTED;
+    a.st = *st;
+    if (a.st.chunks != a.ntd * a.nth * a.ntw || a.st.C != a.Cout) return DEVIS_ERR_BAD_ARG;
+  }
+  if (mode == 1 && ST >= 1) {
+    if (sc) return launch_conv3_k<CIN, COUT_T, TD, TH, TW, S, true, ST >= 1 ? 1 : 0>(a, grid, s);
+    return launch_conv3_k<CIN, COUT_T, TD, TH, TW, S, false, ST >= 1 ? 1 : 0>(a, grid, s);
+  }
+  if (mode == 2 && ST >= 2) return launch_conv3_k<CIN, COUT_T, TD, TH, TW, S, false, ST >= 2 ? 2 : 0>(a, grid, s);
+  if (sc) return launch_conv3_k<CIN, COUT_T, TD, TH, TW, S, true, 0>(a, grid, s);
+  return launch_conv3_k<CIN, COUT_T, TD, TH, TW, S, false, 0>(a, grid, s);
 }
 
 int conv3_c16_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
-                    const float* sh, const void* res, void* y, hipStream_t s);
+                    const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
 
 int conv3_deep(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
-               const float* sh, const void* res, void* y, hipStream_t s);
+               const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
 
 static bool is_3x3x3(const devis_conv_desc* d) {
   return d->KD == 3 && d->KH == 3 && d->KW == 3 && d->PD == 1 && d->PH == 1 && d->PW == 1 && d->SD == d->SH && d->SH == d->SW;
@@ -261,37 +305,44 @@ static bool fits_int(const devis_conv_desc* d) {
   return big < (int64_t)1 << 40 && bigo < (int64_t)1 << 40 && d->N * d->ID * d->IH * d->IW < 0x7fffffff;
 }
 
+// st: statistics to gather in the epilogue (null / mode 0: none).  plan_chunks != null: launch nothing, only
+// report how many statistics chunks per sample the kernel for this shape leaves (0: it cannot gather them).
 int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
-                  const float* sc, const float* sh, const void* res, void* y, hipStream_t s) {
+                  const float* sc, const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks,
+                  hipStream_t s) {
+  if (plan_chunks) *plan_chunks = 0;
   if (d->dtype != DEVIS_BF16 || d->C2 != 0 || x2 || !is_3x3x3(d) || !fits_int(d)) return DEVIS_ERR_UNSUPPORTED;
-  const int ci = (int)d->C1, co = (int)d->Cout, st = d->SD;
-  if (st == 1) {
+  const int ci = (int)d->C1, co = (int)d->Cout, st_ = d->SD;
+#define CONV3(...) launch_conv3<__VA_ARGS__>(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s)
+  if (st_ == 1) {
     static const bool no_march = getenv("DEVIS_NO_MARCH") != nullptr;
-    if (!no_march && co == 16 && (ci == 16 || (ci == 4 && !sc))) return conv3_c16_march(d, x1, w, bias, sc, sh, res, y, s);
+    if (!no_march && co == 16 && (ci == 16 || (ci == 4 && !sc))) return conv3_c16_march(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
     static const bool no_deep = getenv("DEVIS_NO_DEEP") != nullptr;
-    if (!no_deep && ci == co && (ci == 64 || ci == 128)) return conv3_deep(d, x1, w, bias, sc, sh, res, y, s);
-    if (ci == 16 && co == 16) return launch_conv3<16, 16, 8, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
-    if (ci == 4 && co == 16 && !sc) return launch_conv3<16, 16, 8, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
-    if (ci == 32 && co == 32) return launch_conv3<32, 32, 4, 8, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
-    if (ci == 64 && co == 64) return launch_conv3<64, 64, 4, 4, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
-    if (ci == 128 && co == 128) return launch_conv3<128, 32, 2, 4, 16, 1>(d, x1, w, bias, sc, sh, res, y, s);
-    // transposed channel counts (dgrad of the stride-2 layers is not here; these serve generic use)
-  } else if (st == 2) {
-    if (ci == 16 && co == 32) return launch_conv3<16, 32, 2, 4, 16, 2>(d, x1, w, bias, sc, sh, res, y, s);
-    if (ci == 32 && co == 64) return launch_conv3<32, 64, 2, 2, 16, 2>(d, x1, w, bias, sc, sh, res, y, s);
-    if (ci == 64 && co == 128) return launch_conv3<64, 64, 2, 2, 16, 2>(d, x1, w, bias, sc, sh, res, y, s);
+    if (!no_deep && ci == co && (ci == 64 || ci == 128)) return conv3_deep(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
+    if (ci == 16 && co == 16) return CONV3(16, 16, 8, 8, 16, 1);
+    if (ci == 4 && co == 16 && !sc) return CONV3(16, 16, 8, 8, 16, 1);
+    if (ci == 32 && co == 32) return CONV3(32, 32, 4, 8, 16, 1, 2);
+    if (ci == 64 && co == 64) return CONV3(64, 64, 4, 4, 16, 1);
+    if (ci == 128 && co == 128) return CONV3(128, 32, 2, 4, 16, 1);
+  } else if (st_ == 2) {
+    if (ci == 16 && co == 32) return CONV3(16, 32, 2, 4, 16, 2, 1);
+    if (ci == 32 && co == 64) return CONV3(32, 64, 2, 2, 16, 2, 1);
+    if (ci == 64 && co == 128) return CONV3(64, 64, 2, 2, 16, 2, 1);
   }
+#undef CONV3
   return DEVIS_ERR_UNSUPPORTED;
 }
 
 // dgrad of a stride-1 3x3x3 conv = the same conv with flipped taps and swapped channel roles:
 // w_dgrad is [Cin][27][Cout] with tap t' = 26 - t (devis_pack_conv_weight_dgrad).
-int conv_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_dgrad, const void* res, void* dx1, void* dx2, hipStream_t s) {
+int conv_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_dgrad, const void* res, void* dx1, void* dx2,
+                    const StatsArgs* st, int64_t* plan_chunks, hipStream_t s) {
+  if (plan_chunks) *plan_chunks = 0;
   if (!w_dgrad || d->dtype != DEVIS_BF16 || d->C2 != 0 || dx2 || !is_3x3x3(d) || d->SD != 1 || !fits_int(d)) return DEVIS_ERR_UNSUPPORTED;
   devis_conv_desc t = *d;
   t.C1 = d->Cout; t.Cout = d->C1;
   t.ID = d->OD; t.IH = d->OH; t.IW = d->OW; t.OD = d->ID; t.OH = d->IH; t.OW = d->IW;
-  return conv_fwd_mfma(&t, dy, nullptr, w_dgrad, nullptr, nullptr, nullptr, res, dx1, s);
+  return conv_fwd_mfma(&t, dy, nullptr, w_dgrad, nullptr, nullptr, nullptr, res, dx1, st, plan_chunks, s);
 }
 
 }  // namespace devis

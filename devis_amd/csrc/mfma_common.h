@@ -43,4 +43,61 @@ __device__ __forceinline__ u32x4 affine_relu8(u32x4 v, const float* sc, const fl
   return v;
 }
 
+// ---- normalisation statistics gathered in a conv epilogue (no separate pass over the tensor) ----
+// mode 1: per-channel {sum y, sum y^2} of the stored (bf16-rounded) output: GroupNorm/BatchNorm forward moments.
+// mode 2: the kernel runs as a dgrad and y is the gradient w.r.t. relu(scale*xref+shift):
+//         g = y * [scale*xref+shift > 0] -> {sum g, sum g*xref}: the two moments norm backward needs.
+// A block leaves one partial per channel it owns: partial[n][chunk][C][2] (fp64), chunk = its tile index
+// inside sample n -- the layout k_moments writes, so the *_finalize_partials kernels take either.
+struct StatsArgs {
+  int mode;             // 0 = off
+  int chunks;           // chunks per sample (host: must equal the kernel's tiles per sample)
+  int C;                // channels of y
+  double* partial;
+  const bf16* xref;     // mode 2: the tensor the norm was applied to (same shape as y)
+  const float* sc;      // mode 2: [N][C]
+  const float* sh;
+};
+
+// one lane's 4 consecutive channels of one voxel; f0/f1 = running fp32 sums
+template <int STATS>
+__device__ __forceinline__ void stats_accum(uint2 o, uint2 xr, const float* scv, const float* shv, float* f0, float* f1) {
+  const float v[4] = {bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};
+  if (STATS == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f0[j] += v[j]; f1[j] = fmaf(v[j], v[j], f1[j]); }
+  } else if (STATS == 2) {
+    const float x[4] = {bf_lo(xr.x), bf_hi(xr.x), bf_lo(xr.y), bf_hi(xr.y)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = fmaf(x[j], scv[j], shv[j]) > 0.f ? v[j] : 0.f;
+      f0[j] += g;
+      f1[j] = fmaf(g, x[j], f1[j]);
+    }
+  }
+}
+
+// Block-level finish for the MFMA conv kernels' output layout (lane = 4 consecutive cout lq*4.. of m-tile m,
+// voxel l15).  f0/f1[m][j]: the lane's fp32 sums.  Lanes sharing channels combine in fp64 with a fixed xor
+// tree, the four waves through LDS in a fixed order (deterministic).  `red` = >= 4*MT*32 doubles of LDS that
+// no wave still reads (callers barrier before).  pout = &partial[n][chunk][co_base][0].
+template <int MT>
+__device__ __forceinline__ void stats_finish(const float (&f0)[MT][4], const float (&f1)[MT][4], double* red, double* pout) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double a = (double)f0[m][j], b = (double)f1[m][j];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+      if (l15 == 0) {
+        red[((wave * MT + m) * 16 + lq * 4 + j) * 2 + 0] = a;
+        red[((wave * MT + m) * 16 + lq * 4 + j) * 2 + 1] = b;
+      }
+    }
+  __syncthreads();
+  if (tid < MT * 32) pout[tid] = ((red[tid] + red[MT * 32 + tid]) + red[2 * MT * 32 + tid]) + red[3 * MT * 32 + tid];
+}
+
 }  // namespace devis

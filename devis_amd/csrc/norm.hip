@@ -249,6 +249,136 @@ __global__ void k_norm_bwd_finalize(const double* __restrict__ mom, int64_t N, i
   dbeta[c] = (float)db;
 }
 
+// ------------------------------------------------- finalize straight from the per-chunk partials
+// The kernels below fold k_moments_final into the finalize step (one launch instead of two on the serial
+// path of every norm layer).  reduce_chunks() adds the chunk partials of `nout` consecutive doubles starting at
+// partial[n][.][c0][0], for nn samples from n0, into sm[(n - n0) * nout + o], in exactly k_moments_final's order (32 lanes per output, chunk = sub, sub+32, ...; xor tree).
+__device__ __forceinline__ void reduce_chunks(const double* __restrict__ partial, int64_t chunks, int64_t C, int64_t n0,
+                                              int nn, int64_t c0, int nout, double* __restrict__ sm) {
+  const int sub = threadIdx.x & 31;
+  for (int o = threadIdx.x >> 5; o < nn * nout; o += (int)(blockDim.x >> 5)) {
+    const int64_t n = n0 + o / nout;
+    const double* p = partial + (n * chunks * C + c0) * 2 + o % nout;
+    double a = 0.0;
+    for (int64_t k = sub; k < chunks; k += 32) a += p[k * C * 2];
+#pragma unroll
+    for (int w = 1; w < 32; w <<= 1) a += __shfl_xor(a, w, 64);
+    if (sub == 0) sm[o] = a;
+  }
+}
+
+// block = one (n, group)
+__global__ void __launch_bounds__(256)
+k_gn_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
+                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
+                float* __restrict__ rstd) {
+  extern __shared__ double sm[];
+  const int64_t i = blockIdx.x, n = i / G, g = i % G, cpg = C / G;
+  reduce_chunks(partial, chunks, C, n, 1, g * cpg, (int)(cpg * 2), sm);
+  __syncthreads();
+  double s = 0.0, ss = 0.0;
+  for (int64_t c = 0; c < cpg; ++c) { s += sm[c * 2]; ss += sm[c * 2 + 1]; }
+  const double M = (double)cpg * (double)V;
+  const double mu = s / M;
+  double var = ss / M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float r = 1.0f / sqrtf((float)var + eps);
+  if (threadIdx.x == 0) { mean[i] = (float)mu; rstd[i] = r; }
+  for (int64_t c = g * cpg + threadIdx.x; c < (g + 1) * cpg; c += blockDim.x) {
+    const float a = gamma[c] * r;
+    scale[n * C + c] = a;
+    shift[n * C + c] = beta[c] - (float)mu * a;
+  }
+}
+
+// block = one channel (training-mode batch statistics); also bumps num_batches_tracked
+__global__ void __launch_bounds__(256)
+k_bn_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, int64_t V, int64_t C,
+                const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ tracked,
+                float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
+                float* __restrict__ rstd) {
+  extern __shared__ double sm[];
+  const int64_t c = blockIdx.x;
+  reduce_chunks(partial, chunks, C, 0, (int)N, c, 2, sm);
+  __syncthreads();
+  double s = 0.0, ss = 0.0;
+  for (int64_t n = 0; n < N; ++n) { s += sm[n * 2]; ss += sm[n * 2 + 1]; }
+  const double M = (double)N * (double)V;
+  const double m = s / M;
+  double var = ss / M - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)m;
+  const float r = 1.0f / sqrtf((float)var + eps);
+  if (threadIdx.x == 0) {
+    if (rmean) {
+      const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+    if (tracked && c == 0) tracked[0] += 1;
+    mean[c] = mu;
+    rstd[c] = r;
+  }
+  const float a = gamma[c] * r, b = beta[c] - mu * a;
+  for (int64_t n = threadIdx.x; n < N; n += blockDim.x) { scale[n * C + c] = a; shift[n * C + c] = b; }
+}
+
+// block = one channel (BatchNorm) or one group (GroupNorm; all n)
+__global__ void __launch_bounds__(256)
+k_norm_bwd_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
+                      int bn, const float* __restrict__ gamma, const float* __restrict__ mean,
+                      const float* __restrict__ rstd, float* __restrict__ cA, float* __restrict__ cB,
+                      float* __restrict__ cC, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ double sm[];
+  if (bn) {
+    const int64_t c = blockIdx.x;
+    reduce_chunks(partial, chunks, C, 0, (int)N, c, 2, sm);
+    __syncthreads();
+    double m0 = 0.0, m1 = 0.0;
+    for (int64_t n = 0; n < N; ++n) { m0 += sm[n * 2]; m1 += sm[n * 2 + 1]; }
+    const double mu = mean[c], r = rstd[c], gm = gamma[c];
+    const double M = (double)N * (double)V;
+    const double s1 = gm * m0, sxy = gm * m1;
+    const double s2 = r * (sxy - mu * s1);
+    const double B = -r * r * s2 / M;
+    const double Cc = -r * s1 / M - mu * B;
+    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
+      cA[n * C + c] = (float)(gm * r); cB[n * C + c] = (float)B; cC[n * C + c] = (float)Cc;
+    }
+    if (threadIdx.x == 0) { dgamma[c] = (float)(r * (m1 - mu * m0)); dbeta[c] = (float)m0; }
+  } else {
+    const int64_t g = blockIdx.x, cpg = C / G;
+    reduce_chunks(partial, chunks, C, 0, (int)N, g * cpg, (int)(cpg * 2), sm);
+    __syncthreads();
+    const double M = (double)cpg * (double)V;
+    for (int64_t cl = threadIdx.x; cl < cpg; cl += blockDim.x) {
+      const int64_t c = g * cpg + cl;
+      double dg = 0.0, db = 0.0;
+      for (int64_t n = 0; n < N; ++n) {
+        const double* mm = sm + n * cpg * 2;
+        double s1 = 0.0, sxy = 0.0;
+        for (int64_t k = 0; k < cpg; ++k) {
+          s1 += (double)gamma[g * cpg + k] * mm[k * 2];
+          sxy += (double)gamma[g * cpg + k] * mm[k * 2 + 1];
+        }
+        const double mu = mean[n * G + g], r = rstd[n * G + g];
+        const double s2 = r * (sxy - mu * s1);
+        const double B = -r * r * s2 / M;
+        cA[n * C + c] = (float)((double)gamma[c] * r);
+        cB[n * C + c] = (float)B;
+        cC[n * C + c] = (float)(-r * s1 / M - mu * B);
+        const double m0 = mm[cl * 2], m1 = mm[cl * 2 + 1];
+        dg += r * (m1 - mu * m0);
+        db += m0;
+      }
+      dgamma[c] = (float)dg;
+      dbeta[c] = (float)db;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- elementwise
 // one thread per vector of VN channels; flat over N*V*C/VN
 template <typename T, bool RELU, bool RES>
@@ -374,9 +504,11 @@ size_t devis_moments_workspace_bytes(int64_t N, int64_t V, int64_t C) {
   return (size_t)(N * cdiv(V, mom_rows(C, 4)) * C * 2) * sizeof(double);   // fp32 vector width: upper bound for bf16
 }
 
-static int moments_impl(int mode, const void* x, const void* dy, const float* sc, const float* sh, int64_t N,
-                        int64_t V, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes, void* stream) {
-  if (!x || !out || !ws || N <= 0 || V <= 0 || C <= 0 || N > 65535) return DEVIS_ERR_BAD_ARG;
+// first stage only: partial[n][chunk][C][2] in `ws`; *chunks_out = chunks per sample
+static int moments_partials_impl(int mode, const void* x, const void* dy, const float* sc, const float* sh, int64_t N,
+                                 int64_t V, int64_t C, int dtype, void* ws, size_t ws_bytes, int64_t* chunks_out,
+                                 void* stream) {
+  if (!x || !ws || N <= 0 || V <= 0 || C <= 0 || N > 65535) return DEVIS_ERR_BAD_ARG;
   if (!vec_ok(C, dtype)) return DEVIS_ERR_UNSUPPORTED;
   if (ws_bytes < devis_moments_workspace_bytes(N, V, C)) return DEVIS_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -392,10 +524,66 @@ static int moments_impl(int mode, const void* x, const void* dy, const float* sc
     if (mode == 0) hipLaunchKernelGGL((k_moments<T, 0>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, sc, sh, V, C, (int)rows, (double*)ws);
     else hipLaunchKernelGGL((k_moments<T, 1>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, sc, sh, V, C, (int)rows, (double*)ws);
   });
-  int rc = launch_status();
+  *chunks_out = chunks;
+  return launch_status();
+}
+
+static int moments_impl(int mode, const void* x, const void* dy, const float* sc, const float* sh, int64_t N,
+                        int64_t V, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!out) return DEVIS_ERR_BAD_ARG;
+  int64_t chunks = 0;
+  int rc = moments_partials_impl(mode, x, dy, sc, sh, N, V, C, dtype, ws, ws_bytes, &chunks, stream);
   if (rc) return rc;
   const int64_t total = N * C * 2;
-  hipLaunchKernelGGL(k_moments_final, dim3((unsigned)cdiv(total * 32, 256)), dim3(256), 0, s, (const double*)ws, chunks, C, total, out);
+  hipLaunchKernelGGL(k_moments_final, dim3((unsigned)cdiv(total * 32, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)ws, chunks, C, total, out);
+  return launch_status();
+}
+
+int devis_channel_moments_partials(const void* x, int64_t N, int64_t V, int64_t C, int dtype, void* ws,
+                                   size_t ws_bytes, int64_t* chunks_host, void* stream) {
+  if (!chunks_host) return DEVIS_ERR_BAD_ARG;
+  return moments_partials_impl(0, x, nullptr, nullptr, nullptr, N, V, C, dtype, ws, ws_bytes, chunks_host, stream);
+}
+
+int devis_norm_bwd_moments_partials(const void* dy, const void* x, const float* sc, const float* sh, int64_t N,
+                                    int64_t V, int64_t C, int dtype, void* ws, size_t ws_bytes, int64_t* chunks_host,
+                                    void* stream) {
+  if (!dy || !sc || !sh || !chunks_host) return DEVIS_ERR_BAD_ARG;
+  return moments_partials_impl(1, x, dy, sc, sh, N, V, C, dtype, ws, ws_bytes, chunks_host, stream);
+}
+
+#define DEVIS_FINALIZE_SMEM_MAX (48 * 1024)
+
+int devis_gn_finalize_partials(const double* partials, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
+                               const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                               float* mean, float* rstd, void* stream) {
+  if (!partials || chunks <= 0 || !gamma || !beta || !scale || !shift || !mean || !rstd || N <= 0 || V <= 0 || G <= 0 || C % G) return DEVIS_ERR_BAD_ARG;
+  const size_t smem = (size_t)(C / G) * 2 * sizeof(double);
+  if (smem > DEVIS_FINALIZE_SMEM_MAX || N * G > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gn_finalize_p, dim3((unsigned)(N * G)), dim3(256), smem, (hipStream_t)stream, partials, chunks, N, V, C, G, gamma, beta, eps, scale, shift, mean, rstd);
+  return launch_status();
+}
+
+int devis_bn_finalize_partials(const double* partials, int64_t chunks, int64_t N, int64_t V, int64_t C,
+                               const float* gamma, const float* beta, float eps, float momentum, float* rmean,
+                               float* rvar, int64_t* num_batches_tracked, float* scale, float* shift, float* mean,
+                               float* rstd, void* stream) {
+  if (!partials || chunks <= 0 || !gamma || !beta || !scale || !shift || !mean || !rstd || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
+  if ((rmean == nullptr) != (rvar == nullptr)) return DEVIS_ERR_BAD_ARG;
+  const size_t smem = (size_t)N * 2 * sizeof(double);
+  if (smem > DEVIS_FINALIZE_SMEM_MAX || C > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_bn_finalize_p, dim3((unsigned)C), dim3(256), smem, (hipStream_t)stream, partials, chunks, N, V, C, gamma, beta, eps, momentum, rmean, rvar, num_batches_tracked, scale, shift, mean, rstd);
+  return launch_status();
+}
+
+int devis_norm_bwd_finalize_partials(const double* partials, int64_t chunks, int64_t N, int64_t V, int64_t C,
+                                     int64_t G, int bn, const float* gamma, const float* mean, const float* rstd,
+                                     float* cA, float* cB, float* cC, float* dgamma, float* dbeta, void* stream) {
+  if (!partials || chunks <= 0 || !gamma || !mean || !rstd || !cA || !cB || !cC || !dgamma || !dbeta || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
+  if (!bn && (G <= 0 || C % G)) return DEVIS_ERR_BAD_ARG;
+  const size_t smem = (size_t)N * (bn ? 1 : C / G) * 2 * sizeof(double);
+  if (smem > DEVIS_FINALIZE_SMEM_MAX) return DEVIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_norm_bwd_finalize_p, dim3((unsigned)(bn ? C : G)), dim3(256), smem, (hipStream_t)stream, partials, chunks, N, V, C, G, bn, gamma, mean, rstd, cA, cB, cC, dgamma, dbeta);
   return launch_status();
 }
 

@@ -1,8 +1,8 @@
 // Second stage of the deterministic weight-gradient reductions: sums the per-block fp32 partials the
 // wgrad kernels leave in the workspace and scatters the result into the PyTorch weight layout.
-// A block is 64 float4 columns x KG partial groups: lanes run along the partial (coalesced 1 KB reads),
-// wave g adds partials g, g+KG, ... (4 independent loads in flight), the KG waves combine through LDS
-// in a fixed order.  No atomics: the same inputs always give the same bits.
+// A block is LANES float4 columns x KG partial groups: lanes run along the partial (coalesced reads),
+// group g adds partials g, g+KG, ... (4 independent loads in flight), the KG groups combine through LDS
+// in a fixed-shape tree.  No atomics: the same inputs always give the same bits.
 #pragma once
 #include "common.h"
 
@@ -22,30 +22,31 @@ struct RedArgs {
   int A, B, cin_real;   // RED_PW:    o = p*B + mn          -> dw[mn*A + p]   (A = taps T, B = M*N)
 };
 
-#define RED_KG 16
-
-template <int MODE>
-__global__ void __launch_bounds__(64 * RED_KG)
+// LANES float4 columns per block x KG = 1024/LANES partial groups.  Small outputs (a 16x16x27 weight is
+// 1728 columns, a 1x1 weight 128) take narrow blocks so that the launch still covers the chip.
+template <int MODE, int LANES>
+__global__ void __launch_bounds__(1024)
 k_reduce_partials(RedArgs a) {
-  __shared__ float4 red[RED_KG][64];
-  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  constexpr int KG = 1024 / LANES;
+  __shared__ float4 red[1024];
+  const int lane = threadIdx.x % LANES, kg = threadIdx.x / LANES;
   const int64_t n4 = a.total / 4;
-  const int64_t o4 = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t o4 = (int64_t)blockIdx.x * LANES + lane;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (o4 < n4) {
     const float* p = a.part + o4 * 4;
     int k = kg;
-    for (; k + 3 * RED_KG < a.nparts; k += 4 * RED_KG) {
+    for (; k + 3 * KG < a.nparts; k += 4 * KG) {
       const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)k * a.pstride);
-      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(k + RED_KG) * a.pstride);
-      const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(k + 2 * RED_KG) * a.pstride);
-      const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(k + 3 * RED_KG) * a.pstride);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(k + KG) * a.pstride);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(k + 2 * KG) * a.pstride);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(k + 3 * KG) * a.pstride);
       s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
       s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
       s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
       s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
     }
-    for (; k < a.nparts; k += RED_KG) {
+    for (; k < a.nparts; k += KG) {
       const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)k * a.pstride);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -55,16 +56,23 @@ k_reduce_partials(RedArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (c0 + j < a.Cb)
-        for (int k = kg; k < a.nbparts; k += RED_KG) sv[j] += a.bpart[(int64_t)k * a.Cb + c0 + j];
+        for (int k = kg; k < a.nbparts; k += KG) sv[j] += a.bpart[(int64_t)k * a.Cb + c0 + j];
   }
-  red[kg][lane] = s;
+  red[kg * LANES + lane] = s;
   __syncthreads();
-  if (kg != 0) return;
+  // fixed-shape tree over the partial groups: same inputs, same bits
 #pragma unroll
-  for (int j = 1; j < RED_KG; ++j) {
-    const float4 v = red[j][lane];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  for (int h = KG / 2; h >= 1; h >>= 1) {
+    if (kg < h) {
+      float4 u = red[kg * LANES + lane];
+      const float4 v = red[(kg + h) * LANES + lane];
+      u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+      red[kg * LANES + lane] = u;
+    }
+    __syncthreads();
   }
+  if (kg != 0) return;
+  s = red[lane];
   const float* sv = reinterpret_cast<const float*>(&s);
   if (o4 < n4) {
 #pragma unroll
@@ -87,10 +95,18 @@ k_reduce_partials(RedArgs a) {
   }
 }
 
+template <int LANES>
+static inline void launch_reduce_lanes(const RedArgs& a, int64_t n4, hipStream_t s) {
+  const dim3 grid((unsigned)cdiv(n4, LANES));
+  if (a.mode == RED_CONV3) hipLaunchKernelGGL((k_reduce_partials<RED_CONV3, LANES>), grid, dim3(1024), 0, s, a);
+  else hipLaunchKernelGGL((k_reduce_partials<RED_PW, LANES>), grid, dim3(1024), 0, s, a);
+}
+
 static inline int launch_reduce_partials(const RedArgs& a, hipStream_t s) {
   const int64_t n4 = a.total / 4 + (a.dbias ? (a.Cb + 3) / 4 : 0);
-  if (a.mode == RED_CONV3) hipLaunchKernelGGL(k_reduce_partials<RED_CONV3>, dim3((unsigned)cdiv(n4, 64)), dim3(64 * RED_KG), 0, s, a);
-  else hipLaunchKernelGGL(k_reduce_partials<RED_PW>, dim3((unsigned)cdiv(n4, 64)), dim3(64 * RED_KG), 0, s, a);
+  if (n4 >= 64 * 128) launch_reduce_lanes<64>(a, n4, s);
+  else if (n4 >= 16 * 64) launch_reduce_lanes<16>(a, n4, s);
+  else launch_reduce_lanes<4>(a, n4, s);
   return launch_status();
 }
 

@@ -198,9 +198,21 @@ def _out_shape(x: Tensor, osp, cout: int):
     return (x.shape[0],) + (tuple(osp) if x.dim() == 5 else tuple(osp[1:])) + (cout,)
 
 
+def _stats_request(lib, d, dgrad: int, mode: int, pro: bool, res: bool, n: int, c: int, device, xref=None, sc=None, sh=None):
+    """-> (ConvStats | None, (partials, chunks) | None): a statistics request the kernel for this shape honours."""
+    chunks = lib.devis_conv_stats_chunks(C.byref(d), dgrad, mode, int(pro), int(res))
+    if chunks <= 0:
+        return None, None
+    part = torch.empty((n, chunks, c, 2), dtype=torch.float64, device=device)
+    st = _lib.ConvStats(mode, 0, part.data_ptr(), part.numel() * 8, chunks, _p(xref), _p(sc), _p(sh))
+    return st, (part, chunks)
+
+
 def conv_fwd(x1: Tensor, x2: Optional[Tensor], wp: Tensor, bias: Optional[Tensor], geom: ConvGeom,
              scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
-             residual: Optional[Tensor] = None) -> Tensor:
+             residual: Optional[Tensor] = None, want_stats: bool = False):
+    """-> y, or (y, partials | None) with want_stats: the per-chunk moments of y gathered in the conv's epilogue
+    (pass them to gn_stats / bn_stats); None when the kernel for this shape cannot gather them."""
     _need_cuda(x1, x2, wp, bias, scale, shift, residual)
     isp = _spatial(x1)
     c1 = x1.shape[-1]
@@ -219,15 +231,24 @@ def conv_fwd(x1: Tensor, x2: Optional[Tensor], wp: Tensor, bias: Optional[Tensor
         raise _lib.DevisError("residual shape mismatch")
     if scale is not None and scale.numel() != x1.shape[0] * (c1 + c2):
         raise _lib.DevisError("prologue scale must be [N, Cin]")
-    check(_lib.load().devis_conv_fwd(C.byref(d), _p(x1), _p(x2), _p(wp), _p(bias), _p(scale), _p(shift),
-                                     _p(residual), _p(y), _stream()), "conv_fwd")
-    return y
+    lib = _lib.load()
+    if want_stats:
+        st, part = _stats_request(lib, d, 0, 1, scale is not None, residual is not None, x1.shape[0], cout, x1.device)
+        if st is not None:
+            check(lib.devis_conv_fwd_stats(C.byref(d), _p(x1), _p(x2), _p(wp), _p(bias), _p(scale), _p(shift),
+                                           _p(residual), _p(y), C.byref(st), _stream()), "conv_fwd_stats")
+            return y, part
+    check(lib.devis_conv_fwd(C.byref(d), _p(x1), _p(x2), _p(wp), _p(bias), _p(scale), _p(shift),
+                             _p(residual), _p(y), _stream()), "conv_fwd")
+    return (y, None) if want_stats else y
 
 
 def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, residual: Optional[Tensor] = None,
-               wd: Optional[Tensor] = None):
+               wd: Optional[Tensor] = None, norm=None):
     """-> (dx1, dx2|None): gradient w.r.t. the conv's (post-prologue) inputs.  `wd`: the dgrad packing
-    of the weight when the caller already has it (WeightPacker), else it is derived from `wp` here."""
+    of the weight when the caller already has it (WeightPacker), else it is derived from `wp` here.
+    `norm` = (x, scale, shift) of the norm+ReLU whose output fed this conv: returns (dx1, dx2, partials | None)
+    with the norm-backward moments gathered in the epilogue (pass them to norm_relu_bwd)."""
     _need_cuda(dy, wp)
     n = in_shape1[0]
     c1 = in_shape1[-1]
@@ -246,8 +267,19 @@ def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, r
                                                  dt_code(wp.dtype), _stream()), "repack_conv_weight_dgrad")
     if residual is not None and (c2 or residual.shape != dx1.shape):
         raise _lib.DevisError("dgrad residual needs C2 == 0 and the input's shape")
+    if norm is not None:
+        xref, sc, sh = norm
+        _need_cuda(xref, sc, sh)
+        if xref.shape != dx1.shape or xref.dtype != dx1.dtype:
+            raise _lib.DevisError("dgrad statistics: the normalised tensor must have the input's shape and dtype")
+        st, part = (None, None) if c2 else _stats_request(lib, d, 1, 2, False, residual is not None, n, c1, dy.device,
+                                                          xref, sc, sh)
+        if st is not None:
+            check(lib.devis_conv_dgrad_stats(C.byref(d), _p(dy), _p(wp), _p(wd), _p(residual), _p(dx1), _p(dx2),
+                                             C.byref(st), _stream()), "conv_dgrad_stats")
+            return dx1, dx2, part
     check(lib.devis_conv_dgrad(C.byref(d), _p(dy), _p(wp), _p(wd), _p(residual), _p(dx1), _p(dx2), _stream()), "conv_dgrad")
-    return dx1, dx2
+    return (dx1, dx2, None) if norm is not None else (dx1, dx2)
 
 
 def conv_wgrad(x1: Tensor, x2: Optional[Tensor], dy: Tensor, geom: ConvGeom, wshape,
@@ -349,32 +381,59 @@ def _moments(x: Tensor, dy: Optional[Tensor] = None, scale=None, shift=None) -> 
     return out
 
 
-def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 8, eps: float = 1e-5):
-    """GroupNorm statistics -> (scale[N,C], shift[N,C], mean[N,G], rstd[N,G])."""
+def _moment_partials(x: Tensor, dy: Optional[Tensor] = None, scale=None, shift=None):
+    """First reduction stage only -> (workspace holding partial[n][chunk][C][2] fp64, chunks per sample)."""
+    n, v, c = _nvc(x)
+    lib = _lib.load()
+    nb = lib.devis_moments_workspace_bytes(n, v, c)
+    ws = workspace(nb, x.device)
+    chunks = C.c_int64(0)
+    if dy is None:
+        check(lib.devis_channel_moments_partials(_p(x), n, v, c, dt_code(x.dtype), _p(ws), nb, C.byref(chunks),
+                                                 _stream()), "channel_moments_partials")
+    else:
+        check(lib.devis_norm_bwd_moments_partials(_p(dy), _p(x), _p(scale), _p(shift), n, v, c, dt_code(x.dtype),
+                                                  _p(ws), nb, C.byref(chunks), _stream()), "norm_bwd_moments_partials")
+    return ws, chunks.value
+
+
+def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, groups: int = 8, eps: float = 1e-5, partials=None):
+    """GroupNorm statistics -> (scale[N,C], shift[N,C], mean[N,G], rstd[N,G]).  `partials` = (buffer, chunks)
+    when the producing conv already left the per-chunk moments."""
     _need_cuda(x, gamma, beta)
     n, v, c = _nvc(x)
-    mom = _moments(x)
+    ws, chunks = partials if partials is not None else _moment_partials(x)
     f = dict(dtype=torch.float32, device=x.device)
-    scale, shift = torch.empty((n, c), **f), torch.empty((n, c), **f)
-    mean, rstd = torch.empty((n, groups), **f), torch.empty((n, groups), **f)
-    check(_lib.load().devis_gn_finalize(_p(mom), n, v, c, groups, _p(gamma), _p(beta), eps, _p(scale), _p(shift),
-                                        _p(mean), _p(rstd), _stream()), "gn_finalize")
-    return scale, shift, mean, rstd
+    coef = torch.empty((2, n, c), **f)
+    mr = torch.empty((2, n, groups), **f)
+    check(_lib.load().devis_gn_finalize_partials(_p(ws), chunks, n, v, c, groups, _p(gamma), _p(beta), eps,
+                                                 _p(coef[0]), _p(coef[1]), _p(mr[0]), _p(mr[1]), _stream()),
+          "gn_finalize_partials")
+    return coef[0], coef[1], mr[0], mr[1]
 
 
 def bn_stats(x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor, running_var: Tensor, training: bool,
-             momentum: float = 0.1, eps: float = 1e-5):
-    """BatchNorm coefficients; updates the running buffers in place when training."""
-    _need_cuda(x, gamma, beta, running_mean, running_var)
+             momentum: float = 0.1, eps: float = 1e-5, tracked: Optional[Tensor] = None, partials=None):
+    """BatchNorm coefficients; in training mode updates the running buffers (and `tracked`, the
+    num_batches_tracked counter, when given) in place."""
+    _need_cuda(x, gamma, beta, running_mean, running_var, tracked)
     n, v, c = _nvc(x)
-    mom = _moments(x) if training else None
     f = dict(dtype=torch.float32, device=x.device)
-    scale, shift = torch.empty((n, c), **f), torch.empty((n, c), **f)
-    mean, rstd = torch.empty((c,), **f), torch.empty((c,), **f)
-    check(_lib.load().devis_bn_finalize(_p(mom), n, v, c, _p(gamma), _p(beta), eps, momentum, int(training),
-                                        _p(running_mean), _p(running_var), _p(scale), _p(shift), _p(mean), _p(rstd),
-                                        _stream()), "bn_finalize")
-    return scale, shift, mean, rstd
+    coef = torch.empty((2, n, c), **f)
+    mr = torch.empty((2, c), **f)
+    lib = _lib.load()
+    if training:
+        if tracked is not None and tracked.dtype != torch.int64:
+            raise _lib.DevisError("num_batches_tracked must be int64")
+        ws, chunks = partials if partials is not None else _moment_partials(x)
+        check(lib.devis_bn_finalize_partials(_p(ws), chunks, n, v, c, _p(gamma), _p(beta), eps, momentum,
+                                             _p(running_mean), _p(running_var), _p(tracked), _p(coef[0]), _p(coef[1]),
+                                             _p(mr[0]), _p(mr[1]), _stream()), "bn_finalize_partials")
+    else:
+        check(lib.devis_bn_finalize(None, n, v, c, _p(gamma), _p(beta), eps, momentum, 0,
+                                    _p(running_mean), _p(running_var), _p(coef[0]), _p(coef[1]), _p(mr[0]), _p(mr[1]),
+                                    _stream()), "bn_finalize")
+    return coef[0], coef[1], mr[0], mr[1]
 
 
 def affine_act(x: Tensor, scale: Tensor, shift: Tensor, residual: Optional[Tensor] = None, relu: bool = True) -> Tensor:
@@ -387,19 +446,20 @@ def affine_act(x: Tensor, scale: Tensor, shift: Tensor, residual: Optional[Tenso
 
 
 def norm_relu_bwd(dy: Tensor, x: Tensor, scale: Tensor, shift: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
-                  groups: int, bn: bool, extra: Optional[Tensor] = None, out=None):
-    """Backward of relu(norm(x)) -> (dx (+extra), dgamma, dbeta).  `out` = (dgamma, dbeta) buffers to fill."""
+                  groups: int, bn: bool, extra: Optional[Tensor] = None, out=None, partials=None):
+    """Backward of relu(norm(x)) -> (dx (+extra), dgamma, dbeta).  `out` = (dgamma, dbeta) buffers to fill;
+    `partials` = (buffer, chunks) when the kernel that produced dy already left the per-chunk moments."""
     _need_cuda(dy, x, extra)
     n, v, c = _nvc(x)
-    mom = _moments(x, dy, scale, shift)
+    ws, chunks = partials if partials is not None else _moment_partials(x, dy, scale, shift)
     f = dict(dtype=torch.float32, device=x.device)
     coef = torch.empty((3, n, c), **f)
     dgamma, dbeta = out if out is not None else (torch.empty((c,), **f), torch.empty((c,), **f))
     _check_out(dgamma, dbeta)
     lib = _lib.load()
-    check(lib.devis_norm_bwd_finalize(_p(mom), n, v, c, groups, int(bn), _p(gamma), _p(mean), _p(rstd),
-                                      _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(dgamma), _p(dbeta), _stream()),
-          "norm_bwd_finalize")
+    check(lib.devis_norm_bwd_finalize_partials(_p(ws), chunks, n, v, c, groups, int(bn), _p(gamma), _p(mean), _p(rstd),
+                                               _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(dgamma), _p(dbeta), _stream()),
+          "norm_bwd_finalize_partials")
     dx = torch.empty_like(x)
     check(lib.devis_norm_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(coef[0]), _p(coef[1]), _p(coef[2]),
                                    _p(extra), _p(dx), n, v, c, dt_code(x.dtype), _stream()), "norm_bwd_apply")

@@ -41,10 +41,9 @@ class _Run2d:
             self.tape.append(e)
 
     def _bn(self, name, x):
-        if self.training:
-            self.B[name + ".num_batches_tracked"].add_(1)
         return ops.bn_stats(x, self.P[name + ".weight"], self.P[name + ".bias"],
-                            self.B[name + ".running_mean"], self.B[name + ".running_var"], self.training)
+                            self.B[name + ".running_mean"], self.B[name + ".running_var"], self.training,
+                            tracked=self.B[name + ".num_batches_tracked"])
 
     def double_conv(self, name, x1, x2=None):
         P = self.P

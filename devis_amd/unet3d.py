@@ -91,39 +91,44 @@ class _Run:
         if self.taping:
             self.tape.append(entry)
 
-    def _gn(self, name, x):
-        return ops.gn_stats(x, self.P[name + ".weight"], self.P[name + ".bias"])
+    def _gn(self, name, x, partials=None):
+        return ops.gn_stats(x, self.P[name + ".weight"], self.P[name + ".bias"], partials=partials)
 
-    def _bn(self, name, x):
-        if self.training:
-            self.B[name + ".num_batches_tracked"].add_(1)
+    def _bn(self, name, x, partials=None):
         return ops.bn_stats(x, self.P[name + ".weight"], self.P[name + ".bias"],
-                            self.B[name + ".running_mean"], self.B[name + ".running_var"], self.training)
+                            self.B[name + ".running_mean"], self.B[name + ".running_var"], self.training,
+                            tracked=self.B[name + ".num_batches_tracked"], partials=partials)
 
-    # ---- forward blocks
-    def conv(self, name, x, geom):
+    # ---- forward blocks.  A conv whose output feeds a norm gathers that norm's moments in its epilogue
+    # (want_stats); `xs` / the second return value carry those per-chunk partials to the consumer.
+    def conv(self, name, x, geom, want_stats=False):
         wp = self._w(name)
-        y = ops.conv_fwd(x, None, wp, self.P[name + ".bias"], geom)
+        out = ops.conv_fwd(x, None, wp, self.P[name + ".bias"], geom, want_stats=want_stats)
         self._push("conv", name, x, wp, geom)
-        return y
-
-    def en_block(self, name, x):
-        st1 = self._gn(name + ".bn1", x)
-        w1 = self._w(name + ".conv1")
-        h = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G3, st1[0], st1[1])
-        st2 = self._gn(name + ".bn2", h)
-        w2 = self._w(name + ".conv2")
-        out = ops.conv_fwd(h, None, w2, self.P[name + ".conv2.bias"], G3, st2[0], st2[1], residual=x)
-        self._push("en", name, x, h, st1, st2, w1, w2)
         return out
 
-    def de_block(self, name, x):
+    def en_block(self, name, x, xs=None, out_stats=False):
+        st1 = self._gn(name + ".bn1", x, xs)
         w1 = self._w(name + ".conv1")
-        h1 = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G3)
-        st1 = self._bn(name + ".bn1", h1)
+        h, hs = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G3, st1[0], st1[1], want_stats=True)
+        st2 = self._gn(name + ".bn2", h, hs)
         w2 = self._w(name + ".conv2")
-        h2 = ops.conv_fwd(h1, None, w2, self.P[name + ".conv2.bias"], G3, st1[0], st1[1])
-        st2 = self._bn(name + ".bn2", h2)
+        out, os_ = ops.conv_fwd(h, None, w2, self.P[name + ".conv2.bias"], G3, st2[0], st2[1], residual=x,
+                                want_stats=True) if out_stats else \
+            (ops.conv_fwd(h, None, w2, self.P[name + ".conv2.bias"], G3, st2[0], st2[1], residual=x), None)
+        self._push("en", name, x, h, st1, st2, w1, w2)
+        return out, os_
+
+    def de_block(self, name, x):
+        tr = self.training            # eval-mode BatchNorm uses the running statistics: nothing to gather
+        w1 = self._w(name + ".conv1")
+        h1, s1 = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G3, want_stats=True) if tr else \
+            (ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G3), None)
+        st1 = self._bn(name + ".bn1", h1, s1)
+        w2 = self._w(name + ".conv2")
+        h2, s2 = ops.conv_fwd(h1, None, w2, self.P[name + ".conv2.bias"], G3, st1[0], st1[1], want_stats=True) if tr else \
+            (ops.conv_fwd(h1, None, w2, self.P[name + ".conv2.bias"], G3, st1[0], st1[1]), None)
+        st2 = self._bn(name + ".bn2", h2, s2)
         out = ops.affine_act(h2, st2[0], st2[1], residual=x, relu=True)
         self._push("de", name, x, h1, h2, st1, st2, w1, w2)
         return out
@@ -139,17 +144,17 @@ class _Run:
         return y
 
     def forward(self, x: Tensor) -> Tensor:
-        h = self.conv("InitConv.conv", x, G3)
-        s1 = self.en_block("EnBlock1", h)
-        h = self.conv("EnDown1.conv", s1, G3S2)
-        h = self.en_block("EnBlock2_1", h)
-        s2 = self.en_block("EnBlock2_2", h)
-        h = self.conv("EnDown2.conv", s2, G3S2)
-        h = self.en_block("EnBlock3_1", h)
-        s3 = self.en_block("EnBlock3_2", h)
-        h = self.conv("EnDown3.conv", s3, G3S2)
+        h, hs = self.conv("InitConv.conv", x, G3, True)
+        s1, _ = self.en_block("EnBlock1", h, hs)
+        h, hs = self.conv("EnDown1.conv", s1, G3S2, True)
+        h, hs = self.en_block("EnBlock2_1", h, hs, True)
+        s2, _ = self.en_block("EnBlock2_2", h, hs)
+        h, hs = self.conv("EnDown2.conv", s2, G3S2, True)
+        h, hs = self.en_block("EnBlock3_1", h, hs, True)
+        s3, _ = self.en_block("EnBlock3_2", h, hs)
+        h, hs = self.conv("EnDown3.conv", s3, G3S2, True)
         for i in (1, 2, 3, 4):
-            h = self.en_block("EnBlock4_%d" % i, h)
+            h, hs = self.en_block("EnBlock4_%d" % i, h, hs, i < 4)
         h = self.de_block("DeBlock4", self.de_up_cat("DeUpCat4", h, s3))
         h = self.de_block("DeBlock3", self.de_up_cat("DeUpCat3", h, s2))
         h = self.de_block("DeBlock2", self.de_up_cat("DeUpCat2", h, s1))
@@ -172,15 +177,16 @@ class _Run:
         g, P = self.grads, self.P
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
             h, None, dout, G3, P[name + ".conv2.weight"].shape, st2[0], st2[1], out=self._o(name + ".conv2"))
-        da = ops.conv_dgrad(dout, w2, G3, h.shape, wd=self._wd(name + ".conv2"))[0]
+        da, _, pt = ops.conv_dgrad(dout, w2, G3, h.shape, wd=self._wd(name + ".conv2"), norm=(h, st2[0], st2[1]))
         dh, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
-            da, h, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 8, False, out=self._o(name + ".bn2"))
+            da, h, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 8, False, out=self._o(name + ".bn2"),
+            partials=pt)
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
             x, None, dh, G3, P[name + ".conv1.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv1"))
-        da = ops.conv_dgrad(dh, w1, G3, x.shape, wd=self._wd(name + ".conv1"))[0]
+        da, _, pt = ops.conv_dgrad(dh, w1, G3, x.shape, wd=self._wd(name + ".conv1"), norm=(x, st1[0], st1[1]))
         dx, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
             da, x, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 8, False, extra=dout,
-            out=self._o(name + ".bn1"))
+            out=self._o(name + ".bn1"), partials=pt)
         return dx
 
     def _de_bwd(self, e, dout):
@@ -190,9 +196,10 @@ class _Run:
             dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, True, out=self._o(name + ".bn2"))
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
             h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv2"))
-        da = ops.conv_dgrad(dh2, w2, G3, h1.shape, wd=self._wd(name + ".conv2"))[0]
+        da, _, pt = ops.conv_dgrad(dh2, w2, G3, h1.shape, wd=self._wd(name + ".conv2"), norm=(h1, st1[0], st1[1]))
         dh1, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
-            da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, True, out=self._o(name + ".bn1"))
+            da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, True, out=self._o(name + ".bn1"),
+            partials=pt)
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
             x, None, dh1, G3, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
         return ops.conv_dgrad(dh1, w1, G3, x.shape, residual=dout, wd=self._wd(name + ".conv1"))[0]

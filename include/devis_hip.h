@@ -108,6 +108,32 @@ int devis_repack_conv_weight_dgrad(const void* w_packed, void* dst, int64_t Cout
                                    int dtype, void* stream);
 int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w_packed, const void* w_dgrad,
                      const void* residual, void* dx1, void* dx2, void* stream);
+/* Normalisation statistics gathered in the conv epilogue: the conv that PRODUCES a tensor also leaves the
+ * per-channel moments the following nn.GroupNorm / nn.BatchNorm3d needs (UNet3DZoo.py:39-52,149-162), so the
+ * tensor is not read a second time.  partials = [N][chunks][C][2] fp64, the layout of
+ * devis_channel_moments_partials; feed it to devis_{gn,bn,norm_bwd}_finalize_partials.
+ *   mode 1 (forward):  {sum y, sum y^2} of the stored output y.
+ *   mode 2 (dgrad):    dx1 is the gradient w.r.t. relu(scale*x_ref + shift);
+ *                      g = dx1*[scale*x_ref+shift > 0] -> {sum g, sum g*x_ref}  (autograd of norm+ReLU).
+ * devis_conv_stats_chunks: chunks per sample the kernel for this shape leaves, or 0 when that kernel cannot
+ * gather statistics (fp32, shapes served by the direct kernels): then run the conv without statistics and
+ * use devis_channel_moments_partials / devis_norm_bwd_moments_partials.  chunks must be passed back unchanged. */
+typedef struct devis_conv_stats {
+  int32_t mode;            /* 0 none, 1, 2 */
+  int32_t reserved;
+  double* partials;
+  size_t partials_bytes;   /* >= N*chunks*C*2*8 */
+  int64_t chunks;
+  const void* x_ref;       /* mode 2: the normalised tensor, shape of dx1 */
+  const float* scale;      /* mode 2: [N][C] */
+  const float* shift;
+} devis_conv_stats;
+int64_t devis_conv_stats_chunks(const devis_conv_desc* d, int dgrad, int mode, int has_prologue, int has_residual);
+int devis_conv_fwd_stats(const devis_conv_desc* d, const void* x1, const void* x2, const void* w_packed,
+                         const float* bias, const float* in_scale, const float* in_shift, const void* residual,
+                         void* y, const devis_conv_stats* stats, void* stream);
+int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void* w_packed, const void* w_dgrad,
+                           const void* residual, void* dx1, void* dx2, const devis_conv_stats* stats, void* stream);
 /* dw [Cout][C1+C2][T] fp32 (PyTorch layout) and dbias [Cout] fp32 (may be NULL).
  * The conv input is recomputed from x1/x2 with the same prologue. */
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d);
@@ -164,6 +190,27 @@ int devis_norm_bwd_moments(const void* dy, const void* x, const float* scale, co
 int devis_norm_bwd_finalize(const double* moments, int64_t N, int64_t V, int64_t C, int64_t G, int bn,
                             const float* gamma, const float* mean, const float* rstd, float* cA,
                             float* cB, float* cC, float* dgamma, float* dbeta, void* stream);
+/* Two-launch statistics (the training path): the *_partials calls run only the first reduction stage and leave
+ * partial[n][chunk][C][2] (fp64) in `workspace` (*chunks_host = chunks per sample, written on the host);
+ * the *_finalize_partials calls add the chunks in a fixed order and finalize in the same kernel.  Same results
+ * as moments + finalize above (nn.GroupNorm / nn.BatchNorm3d forward and their autograd, UNet3DZoo.py:12,39-52,
+ * 149-162).  devis_bn_finalize_partials is training mode only and also adds 1 to *num_batches_tracked
+ * (int64 device scalar, may be NULL). */
+int devis_channel_moments_partials(const void* x, int64_t N, int64_t V, int64_t C, int dtype, void* workspace,
+                                   size_t workspace_bytes, int64_t* chunks_host, void* stream);
+int devis_norm_bwd_moments_partials(const void* dy, const void* x, const float* scale, const float* shift,
+                                    int64_t N, int64_t V, int64_t C, int dtype, void* workspace,
+                                    size_t workspace_bytes, int64_t* chunks_host, void* stream);
+int devis_gn_finalize_partials(const double* partials, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
+                               const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                               float* mean, float* rstd, void* stream);
+int devis_bn_finalize_partials(const double* partials, int64_t chunks, int64_t N, int64_t V, int64_t C,
+                               const float* gamma, const float* beta, float eps, float momentum,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float* scale, float* shift, float* mean, float* rstd, void* stream);
+int devis_norm_bwd_finalize_partials(const double* partials, int64_t chunks, int64_t N, int64_t V, int64_t C,
+                                     int64_t G, int bn, const float* gamma, const float* mean, const float* rstd,
+                                     float* cA, float* cB, float* cC, float* dgamma, float* dbeta, void* stream);
 /* dx = cA*dy' + cB*x + cC (+ extra): autograd of group_norm/batch_norm + relu (+ skip gradient) */
 int devis_norm_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift,
                          const float* cA, const float* cB, const float* cC, const void* extra, void* dx,
@@ -251,6 +298,15 @@ int devis_evid_infer(const void* logits, int64_t sN, int64_t sV, int64_t sK, int
 /* dz = g * d softplus(z)/dz, fp32 flat arrays: autograd of TMSU.infer (TrustworthySeg.py:160-166)
  * when the evidence is consumed outside the fused loss. */
 int devis_softplus_bwd(const float* z, const float* g, float* dz, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- optimizer -- */
+/* One Adam step with coupled L2 weight decay over flat fp32 arrays of n elements (16-byte aligned), in place:
+ * torch.optim.Adam(model.parameters(), lr, weight_decay=1e-5) as trainUMIS.py:1394 builds it and :261 steps
+ * it, with lr set per iteration by adjust_learning_rate (:217-219).  `step` = 1 for the first update (bias
+ * correction).  Hyper-parameters are doubles because torch derives 1-beta, lr/bias_correction1 and
+ * sqrt(bias_correction2) in double before rounding to fp32. */
+int devis_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, int64_t step, void* stream);
 
 #ifdef __cplusplus
 }

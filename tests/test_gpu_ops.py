@@ -233,3 +233,95 @@ def test_bad_arguments_fail_loudly():
     wp = torch.zeros((16, 27, 8), device="cuda")
     with pytest.raises(_lib.DevisError):
         ops.conv_fwd(x, None, wp, None, ops.ConvGeom((3, 3, 3), (1, 1, 1), (1, 1, 1)))   # channel mismatch
+
+
+# ------------------------------------------------------- statistics gathered in conv epilogues
+STATS_CASES = [
+    # (N, Cin, Cout, spatial, stride): shapes of the bf16 MFMA kernels that gather norm moments
+    (2, 16, 16, (8, 8, 32), 1),      # march 8x32, full tiles
+    (1, 16, 16, (6, 10, 20), 1),     # march 8x32, ragged tiles
+    (2, 16, 16, (20, 16, 16), 1),    # march 16x16, several D chunks
+    (1, 4, 16, (8, 8, 16), 1),       # first layer (Cin = 4)
+    (2, 32, 32, (5, 9, 24), 1),      # generic 32-channel kernel, ragged
+    (2, 64, 64, (4, 8, 16), 1),      # deep 64
+    (1, 128, 128, (4, 4, 16), 1),    # deep 128
+    (1, 16, 32, (8, 8, 32), 2),      # stride-2 (EnDown) variants
+    (2, 32, 64, (8, 8, 16), 2),
+    (1, 64, 128, (4, 8, 16), 2),
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES)
+@pytest.mark.parametrize("prologue,residual", [(False, False), (True, True)])
+def test_conv_epilogue_forward_moments(case, prologue, residual):
+    """conv_fwd(want_stats) leaves per-chunk {sum y, sum y^2}; summed over chunks they equal the moments of
+    the stored bf16 output (fp64 on the CPU) to fp32-accumulation accuracy, and the output is unchanged."""
+    from devis_amd import ops
+    n, ci, co, sp, s = case
+    if ci == 4 and (prologue or residual):
+        pytest.skip("the first layer has neither prologue nor residual")
+    if s == 2 and residual:
+        pytest.skip("stride-2 layers have no residual")
+    g = torch.Generator().manual_seed(11)
+    x = cl(torch.randn((n, ci) + sp, generator=g), torch.bfloat16)
+    w = torch.randn((co, ci, 3, 3, 3), generator=g) * 0.1
+    b = torch.randn((co,), generator=g).cuda()
+    geom = ops.ConvGeom((3, 3, 3), (s,) * 3, (1, 1, 1))
+    wp = ops.pack_conv_weight(w.cuda(), torch.bfloat16)
+    sc = (torch.rand((n, ci), generator=g) + 0.5).cuda() if prologue else None
+    sh = (torch.randn((n, ci), generator=g) * 0.3).cuda() if prologue else None
+    osp = geom.out_spatial(sp)
+    res = cl(torch.randn((n, co) + osp, generator=g), torch.bfloat16) if residual else None
+    y0 = ops.conv_fwd(x, None, wp, b, geom, sc, sh, residual=res)
+    y, part = ops.conv_fwd(x, None, wp, b, geom, sc, sh, residual=res, want_stats=True)
+    assert part is not None, "this shape must gather statistics in the epilogue"
+    assert torch.equal(y, y0)
+    buf, chunks = part
+    assert buf.shape == (n, chunks, co, 2)
+    got = buf.sum(1).cpu()
+    yd = y.double().cpu().reshape(n, -1, co)
+    want = torch.stack([yd.sum(1), (yd * yd).sum(1)], dim=-1)
+    assert rel_err(got[..., 0], want[..., 0]) < 2e-5
+    assert rel_err(got[..., 1], want[..., 1]) < 2e-5
+    # and through the finalize kernel: same scale/shift as the separate-pass statistics
+    gamma, beta = torch.rand(co, generator=g).cuda() + 0.5, torch.randn(co, generator=g).cuda()
+    a = ops.gn_stats(y, gamma, beta, partials=part)
+    r = ops.gn_stats(y, gamma, beta)
+    for u, v in zip(a, r):
+        assert rel_err(u, v) < 1e-4
+
+
+@pytest.mark.parametrize("case", [c for c in STATS_CASES if c[4] == 1 and c[1] == c[2]])
+def test_conv_epilogue_backward_moments(case):
+    """conv_dgrad(norm=(x, scale, shift)) leaves {sum g, sum g*x} with g = dx*[scale*x+shift > 0]: the
+    moments of norm+ReLU backward, equal to the separate pass (devis_norm_bwd_moments_partials)."""
+    from devis_amd import ops
+    n, ci, co, sp, s = case
+    g = torch.Generator().manual_seed(12)
+    dy = cl(torch.randn((n, co) + sp, generator=g), torch.bfloat16)
+    xref = cl(torch.randn((n, ci) + sp, generator=g), torch.bfloat16)
+    w = torch.randn((co, ci, 3, 3, 3), generator=g) * 0.1
+    geom = ops.ConvGeom((3, 3, 3), (1, 1, 1), (1, 1, 1))
+    wp = ops.pack_conv_weight(w.cuda(), torch.bfloat16)
+    sc = (torch.rand((n, ci), generator=g) + 0.5).cuda()
+    sh = (torch.randn((n, ci), generator=g) * 0.3).cuda()
+    dx0, _ = ops.conv_dgrad(dy, wp, geom, xref.shape)
+    dx, _, part = ops.conv_dgrad(dy, wp, geom, xref.shape, norm=(xref, sc, sh))
+    assert part is not None, "this shape must gather statistics in the epilogue"
+    assert torch.equal(dx, dx0)
+    buf, chunks = part
+    got = buf.sum(1).cpu()
+    xd = xref.double().cpu().reshape(n, -1, ci)
+    gate = (xd * sc.double().cpu()[:, None, :] + sh.double().cpu()[:, None, :]) > 0
+    # the kernel gates on fmaf(x, sc, sh) in fp32: evaluate the gate the same way
+    gate = torch.addcmul(sh.cpu()[:, None, :], xref.float().cpu().reshape(n, -1, ci), sc.cpu()[:, None, :]) > 0
+    gd = dx.double().cpu().reshape(n, -1, ci) * gate
+    want = torch.stack([gd.sum(1), (gd * xd).sum(1)], dim=-1)
+    assert rel_err(got[..., 0], want[..., 0]) < 5e-5
+    assert rel_err(got[..., 1], want[..., 1]) < 5e-5
+    gamma = torch.rand(ci, generator=g).cuda() + 0.5
+    mean, rstd = torch.randn((n, 8), generator=g).cuda() * 0.1, torch.rand((n, 8), generator=g).cuda() + 0.5
+    a = ops.norm_relu_bwd(dx, xref, sc, sh, gamma, mean, rstd, 8, False, partials=part)
+    r = ops.norm_relu_bwd(dx, xref, sc, sh, gamma, mean, rstd, 8, False)
+    for u, v in zip(a, r):
+        assert rel_err(u, v) < 2e-2      # dx is bf16; the coefficients agree far tighter (checked above)
