@@ -48,6 +48,9 @@ class _EvidLossFn(torch.autograd.Function):
                                          want_per_voxel=False, ev_shape=(n, k) + sp)
         ctx.save_for_backward(logits, labels, scal)
         ctx.params, ctx.strides = params, strides
+        # the train loop drops `evidence` (trainUMIS.py:255): without this autograd would hand backward a
+        # zero-filled gradient of its size (134 MB at BraTS B=2) for the kernel to read
+        ctx.set_materialize_grads(False)
         loss = scal[0].clone()
         if evidence is None:
             evidence = logits.new_zeros(())
@@ -99,6 +102,7 @@ class _CritFn(torch.autograd.Function):
         scal, _, pv = ops.crit_fwd(params, alpha, strides, labels, evidence_in=ev if has_dice else None,
                                    want_per_voxel=True, want_scal=has_dice)
         ctx.params, ctx.strides, ctx.has_ev = params, strides, (ev is not None and has_dice)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(alpha, ev if ctx.has_ev else None, labels, scal)
         dice = scal[1].clone() if has_dice else alpha.new_zeros(())
         return pv, dice

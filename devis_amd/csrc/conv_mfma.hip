@@ -91,48 +91,65 @@ k_conv3_mfma(Conv3Args a) {
 
   const bf16* wrow = a.w + (size_t)(co_base + l15) * 27 * a.cin_real;
 
-  for (int cc = 0; cc < C::NCH; ++cc) {
-    if (cc > 0) __syncthreads();
-    // ---- stage the halo tile of channels [cc*CK, cc*CK+CK) into LDS (prologue applied, zero padded)
-    {
-      constexpr int PPV = C::CK / 8;      // 16-byte pieces per voxel
-      const int piece = tid % PPV;
-      float scv[8], shv[8];
-      if (PRO) {
+  // ---- halo-tile staging, split in two so that a thread's XPT loads are all in flight together (one load
+  // per loop trip would leave the kernel waiting on HBM latency XPT times per chunk): fetch() issues them into
+  // registers - for chunk cc+1 while the MFMAs of chunk cc run - and stage() applies the norm prologue and
+  // writes LDS.  Slots are per thread and the same for every chunk; out-of-volume slots load a clamped
+  // address and are zeroed by select, so no memory instruction sits under a divergent branch.
+  constexpr int PPV = C::CK / 8;                          // 16-byte pieces per voxel
+  constexpr int XPT = (C::HV * PPV + 255) / 256;
+  const int piece = tid % PPV;
+  const bool cin4 = CIN == 16 && a.cin_real == 4;
+  unsigned xg[XPT], xl[XPT];
+  bool xok[XPT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          scv[j] = a.sc[n * CIN + cc * C::CK + piece * 8 + j];
-          shv[j] = a.sh[n * CIN + cc * C::CK + piece * 8 + j];
-        }
-      }
-      for (int i = tid; i < C::HV * PPV; i += 256) {
-        const int u = i / PPV;
-        const int hw = u % C::HW, hh = (u / C::HW) % C::HH, hd = u / (C::HW * C::HH);
-        const int id = od0 * S - 1 + hd, ih = oh0 * S - 1 + hh, iw = ow0 * S - 1 + hw;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (id >= 0 && id < a.ID && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW) {
-          const size_t vox = (size_t)((n * a.ID + id) * a.IH + ih) * a.IW + iw;
-          if (CIN == 16 && a.cin_real == 4) {
-            if (piece == 0) { const uint2 t = *reinterpret_cast<const uint2*>(a.x + vox * 4); v.x = t.x; v.y = t.y; }
-          } else {
-            v = *reinterpret_cast<const uint4*>(a.x + vox * CIN + cc * C::CK + piece * 8);
-          }
-          if (PRO) {
-            unsigned wds[4] = {v.x, v.y, v.z, v.w};
+  for (int k = 0; k < XPT; ++k) {
+    const int i = tid + k * 256;
+    const int u = i / PPV;
+    const int hw = u % C::HW, hh = (u / C::HW) % C::HH, hd = u / (C::HW * C::HH);
+    const int id = od0 * S - 1 + hd, ih = oh0 * S - 1 + hh, iw = ow0 * S - 1 + hw;
+    xok[k] = i < C::HV * PPV && id >= 0 && id < a.ID && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW && !(cin4 && piece);
+    const unsigned vox = (unsigned)(((n * a.ID + id) * a.IH + ih) * a.IW + iw);
+    xg[k] = xok[k] ? (cin4 ? vox * 4u : vox * (unsigned)CIN + (unsigned)(piece * 8)) : 0u;
+    const int slot = C::CK == 32 ? (piece ^ ((u >> 1) & 3)) : piece;   // XOR swizzle: conflict-free b128 reads
+    xl[k] = (unsigned)(u * C::PITCH + slot * 16);
+  }
+  auto fetch = [&](int cc, u32x4 (&xr)[XPT]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float lo = fmaxf(fmaf(bf_lo(wds[j]), scv[2 * j], shv[2 * j]), 0.f);
-              const float hi = fmaxf(fmaf(bf_hi(wds[j]), scv[2 * j + 1], shv[2 * j + 1]), 0.f);
-              wds[j] = pack_bf2(lo, hi);
-            }
-            v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-          }
-        }
-        const int slot = C::CK == 32 ? (piece ^ ((u >> 1) & 3)) : piece;   // XOR swizzle: conflict-free b128 reads
-        *reinterpret_cast<uint4*>(smem + u * C::PITCH + slot * 16) = v;
+    for (int k = 0; k < XPT; ++k) {
+      if (CIN == 16 && cin4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(a.x + xg[k]);
+        xr[k] = (u32x4){t.x, t.y, 0u, 0u};
+      } else {
+        xr[k] = *reinterpret_cast<const u32x4*>(a.x + xg[k] + cc * C::CK);
       }
     }
+  };
+  auto stage = [&](int cc, u32x4 (&xr)[XPT]) __attribute__((always_inline)) {
+    float scv[8], shv[8];
+    if (PRO) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        scv[j] = a.sc[n * CIN + cc * C::CK + piece * 8 + j];
+        shv[j] = a.sh[n * CIN + cc * C::CK + piece * 8 + j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      u32x4 v = xr[k];
+      if (PRO) v = affine_relu8(v, scv, shv);
+      if (!xok[k]) v = (u32x4){0u, 0u, 0u, 0u};
+      if (k < XPT - 1 || tid + k * 256 < C::HV * PPV) *reinterpret_cast<u32x4*>(smem + xl[k]) = v;
+    }
+  };
+
+  u32x4 xr[XPT];
+  fetch(0, xr);
+  for (int cc = 0; cc < C::NCH; ++cc) {
+    if (cc > 0) __syncthreads();
+    stage(cc, xr);
     __syncthreads();
+    if (cc + 1 < C::NCH) fetch(cc + 1, xr);
 
     // ---- MFMA over the 27 taps of this channel chunk
     if (C::CK == 32) {
@@ -302,7 +319,7 @@ static bool is_3x3x3(const devis_conv_desc* d) {
 static bool fits_int(const devis_conv_desc* d) {
   const int64_t big = d->N * d->ID * d->IH * d->IW * (d->C1 + d->C2);
   const int64_t bigo = d->N * d->OD * d->OH * d->OW * d->Cout;
-  return big < (int64_t)1 << 40 && bigo < (int64_t)1 << 40 && d->N * d->ID * d->IH * d->IW < 0x7fffffff;
+  return big < (int64_t)1 << 32 && bigo < (int64_t)1 << 40 && d->N * d->ID * d->IH * d->IW < 0x7fffffff;
 }
 
 // st: statistics to gather in the epilogue (null / mode 0: none).  plan_chunks != null: launch nothing, only

@@ -252,23 +252,30 @@ __global__ void k_norm_bwd_finalize(const double* __restrict__ mom, int64_t N, i
 // ------------------------------------------------- finalize straight from the per-chunk partials
 // The kernels below fold k_moments_final into the finalize step (one launch instead of two on the serial
 // path of every norm layer).  reduce_chunks() adds the chunk partials of `nout` consecutive doubles starting at
-// partial[n][.][c0][0], for nn samples from n0, into sm[(n - n0) * nout + o], in exactly k_moments_final's order (32 lanes per output, chunk = sub, sub+32, ...; xor tree).
+// partial[n][.][c0][0], for nn samples from n0, into sm[(n - n0) * nout + o].
 __device__ __forceinline__ void reduce_chunks(const double* __restrict__ partial, int64_t chunks, int64_t C, int64_t n0,
                                               int nn, int64_t c0, int nout, double* __restrict__ sm) {
-  const int sub = threadIdx.x & 31;
-  for (int o = threadIdx.x >> 5; o < nn * nout; o += (int)(blockDim.x >> 5)) {
+  // one wave per output, four independent loads in flight per lane, fixed xor tree: deterministic
+  const int sub = threadIdx.x & 63;
+  for (int o = threadIdx.x >> 6; o < nn * nout; o += (int)(blockDim.x >> 6)) {
     const int64_t n = n0 + o / nout;
     const double* p = partial + (n * chunks * C + c0) * 2 + o % nout;
-    double a = 0.0;
-    for (int64_t k = sub; k < chunks; k += 32) a += p[k * C * 2];
+    const int64_t st = C * 2;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t k = sub;
+    for (; k + 192 < chunks; k += 256) {
+      a0 += p[k * st]; a1 += p[(k + 64) * st]; a2 += p[(k + 128) * st]; a3 += p[(k + 192) * st];
+    }
+    for (; k < chunks; k += 64) a0 += p[k * st];
+    double a = (a0 + a1) + (a2 + a3);
 #pragma unroll
-    for (int w = 1; w < 32; w <<= 1) a += __shfl_xor(a, w, 64);
+    for (int w = 1; w < 64; w <<= 1) a += __shfl_xor(a, w, 64);
     if (sub == 0) sm[o] = a;
   }
 }
 
 // block = one (n, group)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_gn_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                 float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
@@ -293,7 +300,7 @@ k_gn_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, i
 }
 
 // block = one channel (training-mode batch statistics); also bumps num_batches_tracked
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_bn_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, int64_t V, int64_t C,
                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                 float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ tracked,
@@ -326,7 +333,7 @@ k_bn_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, i
 }
 
 // block = one channel (BatchNorm) or one group (GroupNorm; all n)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_norm_bwd_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
                       int bn, const float* __restrict__ gamma, const float* __restrict__ mean,
                       const float* __restrict__ rstd, float* __restrict__ cA, float* __restrict__ cB,
@@ -553,6 +560,8 @@ int devis_norm_bwd_moments_partials(const void* dy, const void* x, const float* 
 }
 
 #define DEVIS_FINALIZE_SMEM_MAX (48 * 1024)
+// one wave per output, at most 16 waves
+static inline unsigned fin_threads(int64_t nout) { return (unsigned)(64 * (nout < 1 ? 1 : (nout > 16 ? 16 : nout))); }
 
 int devis_gn_finalize_partials(const double* partials, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
                                const float* gamma, const float* beta, float eps, float* scale, float* shift,
@@ -560,7 +569,7 @@ int devis_gn_finalize_partials(const double* partials, int64_t chunks, int64_t N
   if (!partials || chunks <= 0 || !gamma || !beta || !scale || !shift || !mean || !rstd || N <= 0 || V <= 0 || G <= 0 || C % G) return DEVIS_ERR_BAD_ARG;
   const size_t smem = (size_t)(C / G) * 2 * sizeof(double);
   if (smem > DEVIS_FINALIZE_SMEM_MAX || N * G > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_gn_finalize_p, dim3((unsigned)(N * G)), dim3(256), smem, (hipStream_t)stream, partials, chunks, N, V, C, G, gamma, beta, eps, scale, shift, mean, rstd);
+  hipLaunchKernelGGL(k_gn_finalize_p, dim3((unsigned)(N * G)), dim3(fin_threads((C / G) * 2)), smem, (hipStream_t)stream, partials, chunks, N, V, C, G, gamma, beta, eps, scale, shift, mean, rstd);
   return launch_status();
 }
 
@@ -572,7 +581,7 @@ int devis_bn_finalize_partials(const double* partials, int64_t chunks, int64_t N
   if ((rmean == nullptr) != (rvar == nullptr)) return DEVIS_ERR_BAD_ARG;
   const size_t smem = (size_t)N * 2 * sizeof(double);
   if (smem > DEVIS_FINALIZE_SMEM_MAX || C > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_bn_finalize_p, dim3((unsigned)C), dim3(256), smem, (hipStream_t)stream, partials, chunks, N, V, C, gamma, beta, eps, momentum, rmean, rvar, num_batches_tracked, scale, shift, mean, rstd);
+  hipLaunchKernelGGL(k_bn_finalize_p, dim3((unsigned)C), dim3(fin_threads(N * 2)), smem, (hipStream_t)stream, partials, chunks, N, V, C, gamma, beta, eps, momentum, rmean, rvar, num_batches_tracked, scale, shift, mean, rstd);
   return launch_status();
 }
 
@@ -583,7 +592,7 @@ int devis_norm_bwd_finalize_partials(const double* partials, int64_t chunks, int
   if (!bn && (G <= 0 || C % G)) return DEVIS_ERR_BAD_ARG;
   const size_t smem = (size_t)N * (bn ? 1 : C / G) * 2 * sizeof(double);
   if (smem > DEVIS_FINALIZE_SMEM_MAX) return DEVIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_norm_bwd_finalize_p, dim3((unsigned)(bn ? C : G)), dim3(256), smem, (hipStream_t)stream, partials, chunks, N, V, C, G, bn, gamma, mean, rstd, cA, cB, cC, dgamma, dbeta);
+  hipLaunchKernelGGL(k_norm_bwd_finalize_p, dim3((unsigned)(bn ? C : G)), dim3(fin_threads(N * (bn ? 1 : C / G) * 2)), smem, (hipStream_t)stream, partials, chunks, N, V, C, G, bn, gamma, mean, rstd, cA, cB, cC, dgamma, dbeta);
   return launch_status();
 }
 

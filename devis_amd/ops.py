@@ -283,7 +283,8 @@ def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, r
 
 
 def conv_wgrad(x1: Tensor, x2: Optional[Tensor], dy: Tensor, geom: ConvGeom, wshape,
-               scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, want_bias: bool = True, out=None):
+               scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, want_bias: bool = True, out=None,
+               slot: str = "ws"):
     """-> (dw in the PyTorch layout `wshape` fp32, dbias fp32|None).  `out` = (dw, dbias) buffers to fill
     (views of a flat gradient bucket) instead of fresh tensors."""
     _need_cuda(x1, x2, dy, scale, shift)
@@ -300,7 +301,7 @@ def conv_wgrad(x1: Tensor, x2: Optional[Tensor], dy: Tensor, geom: ConvGeom, wsh
     _check_out(dw, db)
     lib = _lib.load()
     nb = lib.devis_conv_wgrad_workspace_bytes(C.byref(d))
-    ws = workspace(nb, x1.device) if nb else None
+    ws = workspace(nb, x1.device, slot) if nb else None
     check(lib.devis_conv_wgrad(C.byref(d), _p(x1), _p(x2), _p(scale), _p(shift), _p(dy), _p(dw), _p(db),
                                _p(ws), nb, _stream()), "conv_wgrad")
     return dw, db
@@ -345,7 +346,7 @@ def _check_out(*ts) -> None:
             raise _lib.DevisError("gradient output buffers must be contiguous fp32 device tensors")
 
 
-def convT_wgrad(x: Tensor, dy: Tensor, k, wshape, out=None):
+def convT_wgrad(x: Tensor, dy: Tensor, k, wshape, out=None, slot: str = "ws"):
     _need_cuda(x, dy)
     cin, cout = wshape[0], wshape[1]
     d = _tdesc(x.shape, cin, cout, k, x.dtype)
@@ -356,7 +357,7 @@ def convT_wgrad(x: Tensor, dy: Tensor, k, wshape, out=None):
     _check_out(dw, db)
     lib = _lib.load()
     nb = lib.devis_convT_wgrad_workspace_bytes(C.byref(d))
-    ws = workspace(nb, x.device) if nb else None
+    ws = workspace(nb, x.device, slot) if nb else None
     check(lib.devis_convT_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), nb, _stream()), "convT_wgrad")
     return dw, db
 

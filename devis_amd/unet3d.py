@@ -79,6 +79,7 @@ class _Run:
         self.dtype, self.training, self.taping = dtype, training, tape
         self.tape: List = []
         self.grads: Dict[str, Tensor] = {}
+        self.side = None                      # stream the weight-gradient kernels run on during backward (or None)
 
     # ---- helpers
     def _w(self, name):
@@ -165,24 +166,41 @@ class _Run:
         """(buffer for name+a, buffer for name+b): where the kernels write that layer's gradients"""
         return (self.G[name + a], self.G[name + b])
 
+    def _wg(self, fn, *args, **kw):
+        """Run a weight-gradient call.  Nothing on backward's critical path (dgrad -> norm backward -> dgrad ...)
+        reads a weight gradient, so with a side stream they are launched there, behind an event that marks their
+        inputs ready, and fill the CUs the small deep-layer kernels of the main stream leave idle.  Inputs are
+        recorded on the side stream so the caching allocator does not hand their memory out while it still reads."""
+        side = self.side
+        if side is None:
+            return fn(*args, **kw)
+        main = torch.cuda.current_stream()
+        side.wait_event(main.record_event())
+        with torch.cuda.stream(side):
+            out = fn(*args, slot="ws_side", **kw)
+        for t in args:
+            if isinstance(t, Tensor):
+                t.record_stream(side)
+        return out
+
     def _conv_bwd(self, e, dy, need_dx=True, skip=None):
         _, name, x, wp, geom = e
         g = self.grads
-        g[name + ".weight"], g[name + ".bias"] = ops.conv_wgrad(x, None, dy, geom, self.P[name + ".weight"].shape,
-                                                                out=self._o(name))
+        g[name + ".weight"], g[name + ".bias"] = self._wg(ops.conv_wgrad, x, None, dy, geom, self.P[name + ".weight"].shape,
+                                                              out=self._o(name))
         return ops.conv_dgrad(dy, wp, geom, x.shape, residual=skip, wd=self._wd(name))[0] if need_dx else None
 
     def _en_bwd(self, e, dout):
         _, name, x, h, st1, st2, w1, w2 = e
         g, P = self.grads, self.P
-        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
-            h, None, dout, G3, P[name + ".conv2.weight"].shape, st2[0], st2[1], out=self._o(name + ".conv2"))
+        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = self._wg(
+            ops.conv_wgrad, h, None, dout, G3, P[name + ".conv2.weight"].shape, st2[0], st2[1], out=self._o(name + ".conv2"))
         da, _, pt = ops.conv_dgrad(dout, w2, G3, h.shape, wd=self._wd(name + ".conv2"), norm=(h, st2[0], st2[1]))
         dh, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
             da, h, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 8, False, out=self._o(name + ".bn2"),
             partials=pt)
-        g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
-            x, None, dh, G3, P[name + ".conv1.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv1"))
+        g[name + ".conv1.weight"], g[name + ".conv1.bias"] = self._wg(
+            ops.conv_wgrad, x, None, dh, G3, P[name + ".conv1.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv1"))
         da, _, pt = ops.conv_dgrad(dh, w1, G3, x.shape, wd=self._wd(name + ".conv1"), norm=(x, st1[0], st1[1]))
         dx, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
             da, x, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 8, False, extra=dout,
@@ -194,27 +212,27 @@ class _Run:
         g, P = self.grads, self.P
         dh2, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
             dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, True, out=self._o(name + ".bn2"))
-        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.conv_wgrad(
-            h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv2"))
+        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = self._wg(
+            ops.conv_wgrad, h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv2"))
         da, _, pt = ops.conv_dgrad(dh2, w2, G3, h1.shape, wd=self._wd(name + ".conv2"), norm=(h1, st1[0], st1[1]))
         dh1, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
             da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, True, out=self._o(name + ".bn1"),
             partials=pt)
-        g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
-            x, None, dh1, G3, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
+        g[name + ".conv1.weight"], g[name + ".conv1.bias"] = self._wg(
+            ops.conv_wgrad, x, None, dh1, G3, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
         return ops.conv_dgrad(dh1, w1, G3, x.shape, residual=dout, wd=self._wd(name + ".conv1"))[0]
 
     def _up_bwd(self, e, dy):
         _, name, x, prev, t, up, w1, wt, w3 = e
         g, P = self.grads, self.P
-        g[name + ".conv3.weight"], g[name + ".conv3.bias"] = ops.conv_wgrad(
-            prev, up, dy, G1, P[name + ".conv3.weight"].shape, out=self._o(name + ".conv3"))
+        g[name + ".conv3.weight"], g[name + ".conv3.bias"] = self._wg(
+            ops.conv_wgrad, prev, up, dy, G1, P[name + ".conv3.weight"].shape, out=self._o(name + ".conv3"))
         dprev, dup = ops.conv_dgrad(dy, w3, G1, prev.shape, up.shape[-1], wd=self._wd(name + ".conv3"))
-        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = ops.convT_wgrad(
-            t, dup, (2, 2, 2), P[name + ".conv2.weight"].shape, out=self._o(name + ".conv2"))
+        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = self._wg(
+            ops.convT_wgrad, t, dup, (2, 2, 2), P[name + ".conv2.weight"].shape, out=self._o(name + ".conv2"))
         dt = ops.convT_dgrad(dup, wt, (2, 2, 2), t.shape, wt=self._wd(name + ".conv2"))
-        g[name + ".conv1.weight"], g[name + ".conv1.bias"] = ops.conv_wgrad(
-            x, None, dt, G1, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
+        g[name + ".conv1.weight"], g[name + ".conv1.bias"] = self._wg(
+            ops.conv_wgrad, x, None, dt, G1, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
         dx = ops.conv_dgrad(dt, w1, G1, x.shape, wd=self._wd(name + ".conv1"))[0]
         return dx, dprev
 
@@ -222,6 +240,11 @@ class _Run:
         """Mirror of forward(); returns d(input) (or None) and fills self.grads."""
         t = self.tape
         pop = t.pop
+        self.side = _side_stream(dlogits.device)
+        if self.side is not None:
+            for v in self.G.values():             # views of one flat buffer: recording one records the block
+                v.record_stream(self.side)
+                break
         d = self._conv_bwd(pop(), dlogits)                       # endconv
         d = self._de_bwd(pop(), d); d, ds1 = self._up_bwd(pop(), d)   # DeBlock2, DeUpCat2
         d = self._de_bwd(pop(), d); d, ds2 = self._up_bwd(pop(), d)   # DeBlock3, DeUpCat3
@@ -237,12 +260,30 @@ class _Run:
         d = self._conv_bwd(pop(), d, skip=ds1)               # EnDown1
         d = self._en_bwd(pop(), d)                               # EnBlock1
         d = self._conv_bwd(pop(), d, need_dx)                    # InitConv
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
         self._bucket_done(2)
         return d
 
     def _bucket_done(self, i):
         if self.sync is not None:
+            if self.side is not None:             # the bucket's weight gradients come from the side stream
+                torch.cuda.current_stream().wait_stream(self.side)
             self.sync.bucket_ready(i)
+
+
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device):
+    """Per-device stream for the weight-gradient kernels (DEVIS_WGRAD_STREAM=0 keeps everything on one stream)."""
+    import os
+    if device.type != "cuda" or os.environ.get("DEVIS_WGRAD_STREAM", "1") == "0":
+        return None
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = _side_streams[device.index] = torch.cuda.Stream(device)
+    return s
 
 
 class _Unet3dFn(torch.autograd.Function):

@@ -73,8 +73,13 @@ def test_fused_adam_on_the_backbone_reads_the_flat_gradient():
     assert abs(l0 - l1) < 1e-5 * abs(l0)
     for k in sd0:
         if sd0[k].is_floating_point():
-            assert rel_err(sd1[k], sd0[k]) < 2e-5, k      # biases in front of a BatchNorm have |g| ~ 1e-9: sqrt(v) ~ eps, the
-                #                                            update is sensitive to the last bit of v
+            if ".DeBlock" in k and k.endswith(("conv1.bias", "conv2.bias")):
+                # a conv bias in front of a BatchNorm has a zero true gradient; what backward leaves is
+                # rounding noise (|g| ~ 1e-9, not reproducible to the bit between two runs of the fp32
+                # kernels) that Adam normalises to +-lr.  The reference has the same property.
+                assert (sd1[k] - sd0[k]).abs().max().item() <= 2 * 0.002 * 1.0001, k
+                continue
+            assert rel_err(sd1[k], sd0[k]) < 2e-5, k
         else:
             assert torch.equal(sd0[k], sd1[k]), k             # num_batches_tracked
             assert int(sd0[k]) == 1

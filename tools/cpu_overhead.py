@@ -6,7 +6,8 @@ from devis_amd.train import adjust_learning_rate
 args = bench.brats_args(torch.bfloat16)
 torch.manual_seed(0)
 m = TMSU(args); m.train()
-opt = torch.optim.Adam(m.parameters(), lr=args.lr, weight_decay=1e-5)
+from devis_amd.optim import FusedAdam
+opt = FusedAdam(m.parameters(), lr=args.lr, weight_decay=1e-5, module=m)
 g = torch.Generator().manual_seed(1)
 x = torch.randn((2, 4, 128, 128, 128), generator=g).cuda(); y = torch.randint(0, 4, (2, 128, 128, 128), generator=g).cuda()
 def step():
