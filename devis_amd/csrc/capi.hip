@@ -17,7 +17,8 @@ int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void
                     int64_t*, hipStream_t);
 // pointwise_mfma.hip
 int conv1_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const void*, void*, hipStream_t);
-int conv1_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, hipStream_t);
+int conv1_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, const StatsArgs*, int64_t*,
+                     hipStream_t);
 int conv3s2_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
 size_t conv1_wgrad_mfma_workspace(const devis_conv_desc*);
 int conv1_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, float*, float*, void*, size_t, hipStream_t);
@@ -68,6 +69,8 @@ int64_t devis_conv_stats_chunks(const devis_conv_desc* d, int dgrad, int mode, i
   if (dgrad) {
     if (has_prologue) return 0;
     rc = conv_dgrad_mfma(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph), nullptr, &st, &chunks, nullptr);
+    if (rc == DEVIS_ERR_UNSUPPORTED && d->C2 == 0)      // 1x1 layers: the gather-GEMM kernel
+      rc = conv1_dgrad_mfma(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph), nullptr, &st, &chunks, nullptr);
   } else {
     rc = conv_fwd_mfma(d, ph, nullptr, ph, phf, has_prologue ? phf : nullptr, has_prologue ? phf : nullptr,
                        has_residual ? ph : nullptr, const_cast<void*>(ph), &st, &chunks, nullptr);
@@ -109,9 +112,9 @@ int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void*
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   rc = conv_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
-  if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;
-  rc = conv1_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = conv1_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;     // statistics only come from the MFMA kernels
   rc = conv3s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   return conv_dgrad_direct(d, dy, w, residual, dx1, dx2, s);

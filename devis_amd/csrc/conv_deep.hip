@@ -188,6 +188,21 @@ k_conv3_deep(DeepArgs a) {
         }
       }
   }
+  // mode 2 reads the normalised tensor at this lane's outputs: all loads first, then the stores (a load issued
+  // behind a store would wait for it: vmcnt counts both)
+  uint2 xref[MT][NT];
+  if (STATS == 2) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int g = wave * NT + j;
+      const int od = od0 + g / TH, oh = oh0 + g % TH, ow = ow0 + l15;
+      const bool in = od < a.D && oh < a.H && ow < a.W;
+      const size_t vox = in ? (size_t)((n * a.D + od) * a.H + oh) * a.W + ow : 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        xref[m][j] = *reinterpret_cast<const uint2*>(a.st.xref + vox * a.Cout + co_base + m * 16 + lq * 4);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int g = wave * NT + j;
@@ -211,9 +226,7 @@ k_conv3_deep(DeepArgs a) {
       o.y = pack_bf2(v2, v3);
       *reinterpret_cast<uint2*>(a.y + vox * a.Cout + co) = o;
       if (STATS) {
-        uint2 xr = o;
-        if (STATS == 2) xr = *reinterpret_cast<const uint2*>(a.st.xref + vox * a.Cout + co);
-        stats_accum<STATS>(o, xr, scs[m], shs[m], f0[m], f1[m]);
+        stats_accum<STATS>(o, STATS == 2 ? xref[m][j] : o, scs[m], shs[m], f0[m], f1[m]);
       }
     }
   }

@@ -219,6 +219,22 @@ k_conv3_mfma(Conv3Args a) {
         }
       }
   }
+  // mode 2 reads the normalised tensor at this lane's outputs: all loads first, then the stores (a load issued
+  // behind a store would wait for it: vmcnt counts both)
+  uint2 xref[C::MT][C::NT];
+  if (STATS == 2) {
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int g = wave * C::NT + j;
+      const int ltw = g % C::NTW, lth = (g / C::NTW) % TH, ltd = g / (C::NTW * TH);
+      const int od = od0 + ltd, oh = oh0 + lth, ow = ow0 + ltw * 16 + l15;
+      const bool in = od < a.OD && oh < a.OH && ow < a.OW;
+      const size_t vox = in ? (size_t)((n * a.OD + od) * a.OH + oh) * a.OW + ow : 0;
+#pragma unroll
+      for (int m = 0; m < C::MT; ++m)
+        xref[m][j] = *reinterpret_cast<const uint2*>(a.st.xref + vox * a.Cout + co_base + m * 16 + lq * 4);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < C::NT; ++j) {
     const int g = wave * C::NT + j;
@@ -243,9 +259,7 @@ k_conv3_mfma(Conv3Args a) {
       o.y = pack_bf2(v2, v3);
       *reinterpret_cast<uint2*>(a.y + vox * a.Cout + co) = o;
       if (STATS) {
-        uint2 xr = o;
-        if (STATS == 2) xr = *reinterpret_cast<const uint2*>(a.st.xref + vox * a.Cout + co);
-        stats_accum<STATS>(o, xr, scs[m], shs[m], f0[m], f1[m]);
+        stats_accum<STATS>(o, STATS == 2 ? xref[m][j] : o, scs[m], shs[m], f0[m], f1[m]);
       }
     }
   }

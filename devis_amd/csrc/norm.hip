@@ -387,26 +387,64 @@ k_norm_bwd_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_
 }
 
 // ---------------------------------------------------------------- elementwise
-// one thread per vector of VN channels; flat over N*V*C/VN
+// Elementwise passes over a channels-last tensor with per-(n,c) coefficients.  grid = (row chunks, N); a thread
+// owns ONE vector of VN channels for its whole walk, so the coefficients sit in registers (loaded once) and the
+// loop body is loads, a few FMAs and a store - no per-element coefficient loads, no 64-bit divisions.
+// Consecutive threads cover consecutive 16-byte pieces (rows x channel vectors): fully coalesced.
+#define EW_UNROLL 4
+static inline int64_t ew_rows(int64_t N, int64_t V, int64_t C, int vn) {
+  int64_t lpr = C / vn;
+  if (lpr > 256) lpr = 256;
+  const int64_t nsub = 256 / lpr;                      // rows per block per load round
+  int64_t rows = nsub * EW_UNROLL;
+  while (N * cdiv(V, rows) > 4096) rows *= 2;          // ~2-4 k blocks on the big tensors
+  return rows;
+}
+
 template <typename T, bool RELU, bool RES>
 __global__ void __launch_bounds__(256)
 k_affine_act(const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
-             const T* __restrict__ res, T* __restrict__ y, int64_t VC, int64_t C, int64_t nvec) {
+             const T* __restrict__ res, T* __restrict__ y, int64_t V, int64_t C, int rows_per_block) {
   constexpr int VN = Vec<T>::N;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = i * VN;
-    const int64_t n = e / VC, c0 = e % C;
-    float v[VN], r[VN];
-    load_vec<T>(x + e, v);
-    if (RES) load_vec<T>(res + e, r);
+  const int64_t n = blockIdx.y;
+  const int lanes_per_row = (int)(C / VN);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < V ? r0 + rows_per_block : V;
+  for (int cbase = 0; cbase < lanes_per_row; cbase += 256) {
+    const int lpr = lanes_per_row < 256 ? lanes_per_row : 256;
+    const int lane = threadIdx.x % lpr, sub = threadIdx.x / lpr, nsub = 256 / lpr;
+    const int64_t c0 = (int64_t)(cbase + lane) * VN;
+    float scv[VN], shv[VN];
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      float t = fmaf(v[j], sc[n * C + c0 + j], sh[n * C + c0 + j]);
-      if (RELU) t = fmaxf(t, 0.f);
-      if (RES) t += r[j];
-      v[j] = t;
+    for (int j = 0; j < VN; ++j) { scv[j] = sc[n * C + c0 + j]; shv[j] = sh[n * C + c0 + j]; }
+    const T* xb = x + n * V * C + c0;
+    const T* rb = RES ? res + n * V * C + c0 : nullptr;
+    T* yb = y + n * V * C + c0;
+    for (int64_t rb0 = r0 + sub; rb0 < r1; rb0 += (int64_t)nsub * EW_UNROLL) {
+      float v[EW_UNROLL][VN], r[EW_UNROLL][VN];
+#pragma unroll
+      for (int k = 0; k < EW_UNROLL; ++k) {
+        const int64_t row = rb0 + (int64_t)k * nsub;
+        if (row < r1) {
+          load_vec<T>(xb + row * C, v[k]);
+          if (RES) load_vec<T>(rb + row * C, r[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < EW_UNROLL; ++k) {
+        const int64_t row = rb0 + (int64_t)k * nsub;
+        if (row < r1) {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            float t = fmaf(v[k][j], scv[j], shv[j]);
+            if (RELU) t = fmaxf(t, 0.f);
+            if (RES) t += r[k][j];
+            v[k][j] = t;
+          }
+          store_vec<T>(yb + row * C, v[k]);
+        }
+      }
     }
-    store_vec<T>(y + e, v);
   }
 }
 
@@ -414,25 +452,53 @@ template <typename T, bool EXTRA>
 __global__ void __launch_bounds__(256)
 k_norm_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ sc,
                  const float* __restrict__ sh, const float* __restrict__ cA, const float* __restrict__ cB,
-                 const float* __restrict__ cC, const T* __restrict__ extra, T* __restrict__ dx, int64_t VC,
-                 int64_t C, int64_t nvec) {
+                 const float* __restrict__ cC, const T* __restrict__ extra, T* __restrict__ dx, int64_t V,
+                 int64_t C, int rows_per_block) {
   constexpr int VN = Vec<T>::N;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = i * VN;
-    const int64_t n = e / VC, c0 = e % C;
-    float g[VN], xv[VN], ex[VN];
-    load_vec<T>(dy + e, g);
-    load_vec<T>(x + e, xv);
-    if (EXTRA) load_vec<T>(extra + e, ex);
+  const int64_t n = blockIdx.y;
+  const int lanes_per_row = (int)(C / VN);
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < V ? r0 + rows_per_block : V;
+  for (int cbase = 0; cbase < lanes_per_row; cbase += 256) {
+    const int lpr = lanes_per_row < 256 ? lanes_per_row : 256;
+    const int lane = threadIdx.x % lpr, sub = threadIdx.x / lpr, nsub = 256 / lpr;
+    const int64_t c0 = (int64_t)(cbase + lane) * VN;
+    float scv[VN], shv[VN], av[VN], bv[VN], cv[VN];
 #pragma unroll
     for (int j = 0; j < VN; ++j) {
       const int64_t k = n * C + c0 + j;
-      const float gm = fmaf(xv[j], sc[k], sh[k]) > 0.f ? g[j] : 0.f;
-      float t = fmaf(cA[k], gm, fmaf(cB[k], xv[j], cC[k]));
-      if (EXTRA) t += ex[j];
-      g[j] = t;
+      scv[j] = sc[k]; shv[j] = sh[k]; av[j] = cA[k]; bv[j] = cB[k]; cv[j] = cC[k];
     }
-    store_vec<T>(dx + e, g);
+    const T* gb = dy + n * V * C + c0;
+    const T* xb = x + n * V * C + c0;
+    const T* eb = EXTRA ? extra + n * V * C + c0 : nullptr;
+    T* ob = dx + n * V * C + c0;
+    for (int64_t rb0 = r0 + sub; rb0 < r1; rb0 += (int64_t)nsub * EW_UNROLL) {
+      float g[EW_UNROLL][VN], xv[EW_UNROLL][VN], ex[EW_UNROLL][VN];
+#pragma unroll
+      for (int k = 0; k < EW_UNROLL; ++k) {
+        const int64_t row = rb0 + (int64_t)k * nsub;
+        if (row < r1) {
+          load_vec<T>(gb + row * C, g[k]);
+          load_vec<T>(xb + row * C, xv[k]);
+          if (EXTRA) load_vec<T>(eb + row * C, ex[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < EW_UNROLL; ++k) {
+        const int64_t row = rb0 + (int64_t)k * nsub;
+        if (row < r1) {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            const float gm = fmaf(xv[k][j], scv[j], shv[j]) > 0.f ? g[k][j] : 0.f;
+            float t = fmaf(av[j], gm, fmaf(bv[j], xv[k][j], cv[j]));
+            if (EXTRA) t += ex[k][j];
+            g[k][j] = t;
+          }
+          store_vec<T>(ob + row * C, g[k]);
+        }
+      }
+    }
   }
 }
 
@@ -635,13 +701,13 @@ int devis_norm_bwd_finalize(const double* mom, int64_t N, int64_t V, int64_t C, 
 
 int devis_affine_act(const void* x, const float* sc, const float* sh, const void* res, void* y, int64_t N, int64_t V,
                      int64_t C, int dtype, int relu, void* stream) {
-  if (!x || !sc || !sh || !y || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
-  const int vn = dtype == DEVIS_F32 ? 4 : 8;
-  if (C % vn) return DEVIS_ERR_UNSUPPORTED;
-  const int64_t nvec = N * V * C / vn;
+  if (!x || !sc || !sh || !y || N <= 0 || V <= 0 || C <= 0 || N > 65535) return DEVIS_ERR_BAD_ARG;
+  if (!vec_ok(C, dtype)) return DEVIS_ERR_UNSUPPORTED;
+  const int64_t rows = ew_rows(N, V, C, dtype == DEVIS_F32 ? 4 : 8);
+  if (cdiv(V, rows) > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(ew_grid(nvec));
-#define LAUNCH_AA(R, S) hipLaunchKernelGGL((k_affine_act<T, R, S>), grid, dim3(256), 0, s, (const T*)x, sc, sh, (const T*)res, (T*)y, V * C, C, nvec)
+  const dim3 grid((unsigned)cdiv(V, rows), (unsigned)N);
+#define LAUNCH_AA(R, S) hipLaunchKernelGGL((k_affine_act<T, R, S>), grid, dim3(256), 0, s, (const T*)x, sc, sh, (const T*)res, (T*)y, V, C, (int)rows)
   DEVIS_DISPATCH_DTYPE(dtype, {
     if (relu && res) LAUNCH_AA(true, true);
     else if (relu) LAUNCH_AA(true, false);
@@ -655,15 +721,15 @@ int devis_affine_act(const void* x, const float* sc, const float* sh, const void
 int devis_norm_bwd_apply(const void* dy, const void* x, const float* sc, const float* sh, const float* cA,
                          const float* cB, const float* cC, const void* extra, void* dx, int64_t N, int64_t V,
                          int64_t C, int dtype, void* stream) {
-  if (!dy || !x || !sc || !sh || !cA || !cB || !cC || !dx || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
-  const int vn = dtype == DEVIS_F32 ? 4 : 8;
-  if (C % vn) return DEVIS_ERR_UNSUPPORTED;
-  const int64_t nvec = N * V * C / vn;
+  if (!dy || !x || !sc || !sh || !cA || !cB || !cC || !dx || N <= 0 || V <= 0 || C <= 0 || N > 65535) return DEVIS_ERR_BAD_ARG;
+  if (!vec_ok(C, dtype)) return DEVIS_ERR_UNSUPPORTED;
+  const int64_t rows = ew_rows(N, V, C, dtype == DEVIS_F32 ? 4 : 8);
+  if (cdiv(V, rows) > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(ew_grid(nvec));
+  const dim3 grid((unsigned)cdiv(V, rows), (unsigned)N);
   DEVIS_DISPATCH_DTYPE(dtype, {
-    if (extra) hipLaunchKernelGGL((k_norm_bwd_apply<T, true>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, sc, sh, cA, cB, cC, (const T*)extra, (T*)dx, V * C, C, nvec);
-    else hipLaunchKernelGGL((k_norm_bwd_apply<T, false>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, sc, sh, cA, cB, cC, (const T*)extra, (T*)dx, V * C, C, nvec);
+    if (extra) hipLaunchKernelGGL((k_norm_bwd_apply<T, true>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, sc, sh, cA, cB, cC, (const T*)extra, (T*)dx, V, C, (int)rows);
+    else hipLaunchKernelGGL((k_norm_bwd_apply<T, false>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, sc, sh, cA, cB, cC, (const T*)extra, (T*)dx, V, C, (int)rows);
   });
   return launch_status();
 }

@@ -22,6 +22,9 @@ struct PwArgs {
   int OD, OH, OW;        // s2 dgrad: coarse (dy) grid;  ConvT: fine (output) grid
   int ntw;               // 16-voxel tiles per row
   int64_t ntiles;
+  StatsArgs st;          // PW_CONV1 only: norm-backward moments gathered in the epilogue (mode 2), see mfma_common.h
+  int blocks_per_n;      // with st: blocks per sample (host guarantees blocks do not straddle samples)
+  int iters;             // with st: groups of 4*NT tiles a block walks
 };
 
 // 8 channels [c, c+8) of a row holding C channels (C % 4 == 0), zero-extended past the end
@@ -75,16 +78,33 @@ __device__ __forceinline__ uint4 pw_load_a(const PwArgs& a, int m, int k0, int c
   return *reinterpret_cast<const uint4*>(a.w + ((size_t)m * 27 + (26 - t)) * a.Cs + c);   // tap-flipped dgrad packing
 }
 
-template <int MODE, int MTP, int NT>
+template <int MODE, int MTP, int NT, int STATS = 0>
 __global__ void __launch_bounds__(256)
 k_pw_mfma(PwArgs a) {
+  __shared__ double stat_red[STATS ? 4 * MTP * 32 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
+  // with statistics a block walks `iters` consecutive groups of 4*NT tiles (same sample), so that the fp64
+  // reduction at the end is paid once per iters*4*NT*16 voxels; otherwise iters = 1
+  const int iters = STATS ? a.iters : 1;
+  float f0[MTP][4], f1[MTP][4], scs[MTP][4], shs[MTP][4];
+  if (STATS) {
+    const int n_blk = (int)(blockIdx.x / a.blocks_per_n);      // a block never straddles samples (host)
+#pragma unroll
+    for (int m = 0; m < MTP; ++m)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f0[m][k] = 0.f; f1[m][k] = 0.f;
+        scs[m][k] = a.st.sc[n_blk * a.M + m * 16 + lq * 4 + k];
+        shs[m][k] = a.st.sh[n_blk * a.M + m * 16 + lq * 4 + k];
+      }
+  }
+  for (int it = 0; it < iters; ++it) {
   int nn[NT], dd[NT], hh[NT], ww[NT];
   bool ok[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int64_t tile = ((int64_t)blockIdx.x * 4 + wave) * NT + j;
+    const int64_t tile = (((int64_t)blockIdx.x * iters + it) * 4 + wave) * NT + j;
     const bool tv = tile < a.ntiles;
     const int64_t tt = tv ? tile : 0;
     const int twi = (int)(tt % a.ntw);
@@ -112,6 +132,20 @@ k_pw_mfma(PwArgs a) {
     for (int m = 0; m < MTP; ++m)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // statistics: the normalised tensor at this lane's outputs, fetched with the operands (a load issued
+    // after the epilogue's stores would wait for them: vmcnt counts both)
+    uint2 xref[MTP][NT];
+    if (STATS == 2 && MODE == PW_CONV1) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const size_t v = ((size_t)(nn[j] * a.D + dd[j]) * a.H + hh[j]) * a.W + ww[j];
+#pragma unroll
+        for (int m = 0; m < MTP; ++m) {
+          const int mrow = m0 + m * 16 + lq * 4;
+          xref[m][j] = (ok[j] && mrow < a.M) ? *reinterpret_cast<const uint2*>(a.st.xref + v * a.M + mrow) : make_uint2(0u, 0u);
+        }
+      }
+    }
     for (int kc = 0; kc < kchunks; ++kc) {
       const int k0 = kc * 32 + lq * 8;
       union { uint4 u; bf16x8 v; } af[MTP], bf[NT];
@@ -169,10 +203,49 @@ k_pw_mfma(PwArgs a) {
         o.x = pack_bf2(v0, v1);
         o.y = pack_bf2(v2, v3);
         *reinterpret_cast<uint2*>(dst) = o;
+        if (STATS == 2 && MODE == PW_CONV1) stats_accum<2>(o, xref[m][j], scs[m], shs[m], f0[m], f1[m]);
       }
     }
   }
   }
+  }
+  if (STATS) {       // host: M <= MTP*16, one m0 pass
+    const int n_blk = (int)(blockIdx.x / a.blocks_per_n), chunk = (int)(blockIdx.x % a.blocks_per_n);
+    stats_finish<MTP>(f0, f1, stat_red, a.st.partial + ((size_t)n_blk * a.st.chunks + chunk) * a.M * 2);
+  }
+}
+
+// tiles per block of the launch pw_launch picks for M output rows
+// (8 tiles per wave for the one-K-chunk layers was measured and is slower: 1x1 64 -> 89 us, stride-2 dgrad
+// 154 -> 184 us at 128^3; kept as a switch)
+static inline bool pw_wide(int M, int64_t ntiles) { (void)M; (void)ntiles; return false; }
+static inline int pw_tiles_per_block(int M, int64_t ntiles) { return cdiv(M, 16) >= 4 ? 8 : (pw_wide(M, ntiles) ? 32 : 16); }
+
+// PW_CONV1 with norm-backward statistics: plan_chunks != null only reports the chunks per sample (0: cannot)
+static int pw_launch_stats(PwArgs& a, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s) {
+  a.ntw = (int)cdiv(a.W, 16);
+  a.ntiles = (int64_t)a.N * a.D * a.H * a.ntw;
+  const int64_t tiles_per_n = (int64_t)a.D * a.H * a.ntw;
+  const int tpb = pw_tiles_per_block(a.M, a.ntiles);
+  bool can = st->mode == 2 && a.M1 == a.M && a.M % 16 == 0 && a.M <= 64 && tiles_per_n % tpb == 0 && a.W % 16 == 0;
+  // groups per block: as many as keep >= 1024 blocks in the launch and divide a sample's groups
+  int iters = 2;
+  while (iters > 1 && ((tiles_per_n / tpb) % iters != 0 || a.ntiles / tpb / iters < 1024)) iters >>= 1;
+  const int64_t bpn = tiles_per_n / tpb / iters;
+  can = can && bpn >= 1 && bpn <= 0x7fffffff;
+  if (plan_chunks) { *plan_chunks = can ? bpn : 0; return DEVIS_OK; }
+  if (!can) return DEVIS_ERR_UNSUPPORTED;
+  a.st = *st;
+  a.blocks_per_n = (int)bpn;
+  a.iters = iters;
+  if (a.st.chunks != a.blocks_per_n || a.st.C != a.M) return DEVIS_ERR_BAD_ARG;
+  const dim3 grid((unsigned)(bpn * a.N));
+  const int mt = (int)cdiv(a.M, 16);
+  if (mt >= 4) hipLaunchKernelGGL((k_pw_mfma<PW_CONV1, 4, 2, 2>), grid, dim3(256), 0, s, a);
+  else if (mt >= 2) hipLaunchKernelGGL((k_pw_mfma<PW_CONV1, 2, 4, 2>), grid, dim3(256), 0, s, a);
+  else if (pw_wide(a.M, a.ntiles)) hipLaunchKernelGGL((k_pw_mfma<PW_CONV1, 1, 8, 2>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_pw_mfma<PW_CONV1, 1, 4, 2>), grid, dim3(256), 0, s, a);
+  return launch_status();
 }
 
 template <int MODE>
@@ -186,6 +259,9 @@ static int pw_launch(PwArgs& a, int ngrid_y, hipStream_t s) {
   } else if (mt >= 2) {
     const dim3 grid((unsigned)cdiv(a.ntiles, 4 * 4), (unsigned)ngrid_y);
     hipLaunchKernelGGL((k_pw_mfma<MODE, 2, 4>), grid, dim3(256), 0, s, a);
+  } else if (pw_wide(a.M, a.ntiles)) {
+    const dim3 grid((unsigned)cdiv(a.ntiles, 4 * 8), (unsigned)ngrid_y);
+    hipLaunchKernelGGL((k_pw_mfma<MODE, 1, 8>), grid, dim3(256), 0, s, a);
   } else {
     const dim3 grid((unsigned)cdiv(a.ntiles, 4 * 4), (unsigned)ngrid_y);
     hipLaunchKernelGGL((k_pw_mfma<MODE, 1, 4>), grid, dim3(256), 0, s, a);
@@ -212,7 +288,8 @@ int conv1_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, con
 
 // ---- 1x1 conv dgrad: (dx1, dx2) = W^T dy; w_t is [Cin][Cout] (devis_repack_conv_weight_dgrad with T = 1)
 int conv1_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_t, const void* res, void* dx1, void* dx2,
-                     hipStream_t s) {
+                     const StatsArgs* st, int64_t* plan_chunks, hipStream_t s) {
+  if (plan_chunks) *plan_chunks = 0;
   if (!w_t || d->dtype != DEVIS_BF16 || d->KD != 1 || d->KH != 1 || d->KW != 1 || d->SD != 1 || d->SH != 1 || d->SW != 1) return DEVIS_ERR_UNSUPPORTED;
   if (d->PD || d->PH || d->PW) return DEVIS_ERR_UNSUPPORTED;
   if (d->Cout % 4 || d->C1 % 16 || d->C2 % 4) return DEVIS_ERR_UNSUPPORTED;    // M tiles must not straddle dx1/dx2
@@ -222,6 +299,10 @@ int conv1_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_t, 
   a.y1 = (bf16*)dx1; a.y2 = (bf16*)dx2;
   a.C1 = (int)d->Cout; a.C2 = 0; a.K = a.C1; a.M = (int)(d->C1 + d->C2); a.M1 = (int)d->C1;
   a.N = (int)d->N; a.D = (int)d->ID; a.H = (int)d->IH; a.W = (int)d->IW;
+  if ((st && st->mode) || plan_chunks) {
+    if (!st || res) { if (plan_chunks) return DEVIS_OK; return DEVIS_ERR_UNSUPPORTED; }
+    return pw_launch_stats(a, st, plan_chunks, s);
+  }
   return pw_launch<PW_CONV1>(a, 1, s);
 }
 

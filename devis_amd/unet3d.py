@@ -183,11 +183,21 @@ class _Run:
                 t.record_stream(side)
         return out
 
-    def _conv_bwd(self, e, dy, need_dx=True, skip=None):
+    def _next_norm(self):
+        """(h2, scale, shift) of the DeBlock whose backward comes next on the tape: its bn2+ReLU backward needs
+        {sum g, sum g*h2} of the gradient the CURRENT layer's dgrad is about to produce, so that dgrad gathers them."""
+        e = self.tape[-1] if self.tape else None
+        return (e[4], e[6][0], e[6][1]) if e is not None and e[0] == "de" else None
+
+    def _conv_bwd(self, e, dy, need_dx=True, skip=None, norm=None):
+        """-> dx, or (dx, partials) with `norm`"""
         _, name, x, wp, geom = e
         g = self.grads
         g[name + ".weight"], g[name + ".bias"] = self._wg(ops.conv_wgrad, x, None, dy, geom, self.P[name + ".weight"].shape,
                                                               out=self._o(name))
+        if norm is not None:
+            dx, _, pt = ops.conv_dgrad(dy, wp, geom, x.shape, residual=skip, wd=self._wd(name), norm=norm)
+            return dx, pt
         return ops.conv_dgrad(dy, wp, geom, x.shape, residual=skip, wd=self._wd(name))[0] if need_dx else None
 
     def _en_bwd(self, e, dout):
@@ -207,11 +217,12 @@ class _Run:
             out=self._o(name + ".bn1"), partials=pt)
         return dx
 
-    def _de_bwd(self, e, dout):
+    def _de_bwd(self, e, dout, partials=None):
         _, name, x, h1, h2, st1, st2, w1, w2 = e
         g, P = self.grads, self.P
         dh2, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
-            dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, True, out=self._o(name + ".bn2"))
+            dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, True, out=self._o(name + ".bn2"),
+            partials=partials)
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = self._wg(
             ops.conv_wgrad, h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv2"))
         da, _, pt = ops.conv_dgrad(dh2, w2, G3, h1.shape, wd=self._wd(name + ".conv2"), norm=(h1, st1[0], st1[1]))
@@ -233,8 +244,12 @@ class _Run:
         dt = ops.convT_dgrad(dup, wt, (2, 2, 2), t.shape, wt=self._wd(name + ".conv2"))
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = self._wg(
             ops.conv_wgrad, x, None, dt, G1, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
-        dx = ops.conv_dgrad(dt, w1, G1, x.shape, wd=self._wd(name + ".conv1"))[0]
-        return dx, dprev
+        norm = self._next_norm()
+        if norm is not None:
+            dx, _, pt = ops.conv_dgrad(dt, w1, G1, x.shape, wd=self._wd(name + ".conv1"), norm=norm)
+        else:
+            dx, pt = ops.conv_dgrad(dt, w1, G1, x.shape, wd=self._wd(name + ".conv1"))[0], None
+        return dx, dprev, pt
 
     def backward(self, dlogits: Tensor, need_dx: bool):
         """Mirror of forward(); returns d(input) (or None) and fills self.grads."""
@@ -245,10 +260,11 @@ class _Run:
             for v in self.G.values():             # views of one flat buffer: recording one records the block
                 v.record_stream(self.side)
                 break
-        d = self._conv_bwd(pop(), dlogits)                       # endconv
-        d = self._de_bwd(pop(), d); d, ds1 = self._up_bwd(pop(), d)   # DeBlock2, DeUpCat2
-        d = self._de_bwd(pop(), d); d, ds2 = self._up_bwd(pop(), d)   # DeBlock3, DeUpCat3
-        d = self._de_bwd(pop(), d); d, ds3 = self._up_bwd(pop(), d)   # DeBlock4, DeUpCat4
+        e = pop()
+        d, pt = self._conv_bwd(e, dlogits, norm=self._next_norm())    # endconv (+ moments for DeBlock2.bn2)
+        d = self._de_bwd(pop(), d, pt); d, ds1, pt = self._up_bwd(pop(), d)   # DeBlock2, DeUpCat2
+        d = self._de_bwd(pop(), d, pt); d, ds2, pt = self._up_bwd(pop(), d)   # DeBlock3, DeUpCat3
+        d = self._de_bwd(pop(), d, pt); d, ds3, _ = self._up_bwd(pop(), d)    # DeBlock4, DeUpCat4
         self._bucket_done(0)                                     # every decoder gradient is final
         for _ in range(4):
             d = self._en_bwd(pop(), d)                           # EnBlock4_4..1

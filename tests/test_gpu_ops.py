@@ -291,17 +291,22 @@ def test_conv_epilogue_forward_moments(case, prologue, residual):
         assert rel_err(u, v) < 1e-4
 
 
-@pytest.mark.parametrize("case", [c for c in STATS_CASES if c[4] == 1 and c[1] == c[2]])
+# 1x1 layers whose dgrad feeds a DeBlock's bn2 backward: endconv (16 -> 4) and DeUpCat.conv1 (2C -> C)
+PW_STATS_CASES = [(2, 16, 4, (8, 8, 16), 0), (1, 32, 16, (4, 8, 16), 0), (2, 64, 32, (4, 4, 16), 0), (2, 16, 4, (32, 32, 32), 0)]
+
+
+@pytest.mark.parametrize("case", [c for c in STATS_CASES if c[4] == 1 and c[1] == c[2]] + PW_STATS_CASES)
 def test_conv_epilogue_backward_moments(case):
     """conv_dgrad(norm=(x, scale, shift)) leaves {sum g, sum g*x} with g = dx*[scale*x+shift > 0]: the
     moments of norm+ReLU backward, equal to the separate pass (devis_norm_bwd_moments_partials)."""
     from devis_amd import ops
     n, ci, co, sp, s = case
+    k = 3 if s else 1                  # s == 0 marks the 1x1 cases
     g = torch.Generator().manual_seed(12)
     dy = cl(torch.randn((n, co) + sp, generator=g), torch.bfloat16)
     xref = cl(torch.randn((n, ci) + sp, generator=g), torch.bfloat16)
-    w = torch.randn((co, ci, 3, 3, 3), generator=g) * 0.1
-    geom = ops.ConvGeom((3, 3, 3), (1, 1, 1), (1, 1, 1))
+    w = torch.randn((co, ci, k, k, k), generator=g) * 0.1
+    geom = ops.ConvGeom((k, k, k), (1, 1, 1), (k // 2,) * 3)
     wp = ops.pack_conv_weight(w.cuda(), torch.bfloat16)
     sc = (torch.rand((n, ci), generator=g) + 0.5).cuda()
     sh = (torch.randn((n, ci), generator=g) * 0.3).cuda()
