@@ -102,6 +102,8 @@ SIGNATURES = {
     "devis_evid_crit_fwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     "devis_evid_crit_bwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devis_evid_infer": (_I, [_P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "devis_eval_counts_workspace_bytes": (_SZ, [_I64]),
+    "devis_eval_counts": (_I, [_P, _P, _I, _P, _I, _P, _I64, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "devis_adam_step": (_I, [_P, _P, _P, _P, _I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _P]),
     "devis_softplus_bwd": (_I, [_P, _P, _P, _I64, _P]),
 }

@@ -611,6 +611,34 @@ def evid_infer(logits: Tensor, channels_last: bool, thresholds: Sequence[float] 
     return dict(evidence=evidence, pred=pred, u=u, mne=mne, umask=umask)
 
 
+def eval_counts(pred: Tensor, target: Tensor, num_classes: int, umask: Optional[Tensor] = None, n_thr: int = 0,
+                u: Optional[Tensor] = None):
+    """Device-side counts behind the reference's val()/test() metrics -> dict(conf (K,K) int64 [target, pred],
+    ucount (n_thr, 8) int64 | None, sums (3,) fp64 | None, bad (1,) int32).  Nothing is copied to the host."""
+    _need_cuda(pred, target, umask, u)
+    if pred.dtype != torch.uint8:
+        raise _lib.DevisError("pred must be uint8 (devis_evid_infer's output)")
+    nv = pred.numel()
+    if target.numel() != nv or (umask is not None and umask.numel() != nv) or (u is not None and u.numel() != nv):
+        raise _lib.DevisError("eval_counts: pred, target, umask and u must have one entry per voxel")
+    if umask is not None and umask.dtype != torch.int16:
+        raise _lib.DevisError("umask must be int16 (devis_evid_infer's output)")
+    if u is not None and u.dtype != torch.float32:
+        raise _lib.DevisError("u must be fp32")
+    dev = pred.device
+    conf = torch.empty((num_classes, num_classes), dtype=torch.int64, device=dev)
+    ucount = torch.empty((n_thr, 8), dtype=torch.int64, device=dev) if n_thr else None
+    sums = torch.empty((3,), dtype=torch.float64, device=dev) if u is not None else None
+    bad = torch.empty((1,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    nb = lib.devis_eval_counts_workspace_bytes(nv)
+    ws = workspace(nb, dev)
+    check(lib.devis_eval_counts(_p(pred), _p(target), _label_code(target), _p(umask) if n_thr else None, n_thr, _p(u), nv,
+                                num_classes, _p(conf), _p(ucount), _p(sums), _p(bad), _p(ws), nb, _stream()),
+          "eval_counts")
+    return dict(conf=conf, ucount=ucount, sums=sums, bad=bad)
+
+
 def softplus_bwd(z: Tensor, g: Tensor) -> Tensor:
     _need_cuda(z, g)
     dz = torch.empty_like(z)

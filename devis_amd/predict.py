@@ -94,3 +94,58 @@ def sliding_window_infer(x, backbone, thresholds=(), rank: int = 0, world: int =
             else:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return out
+
+
+# ------------------------------------------------------------------ evaluation metrics from device-side counts
+# The reference computes these with numpy on host copies of the volumes (predict.py:296-300,386-416;
+# numpyfunctions.py:86-107).  Here they are ratios of the integer counts ops.eval_counts() reduces on the
+# GPU (csrc/evalmaps.hip): `conf[t, p]` = voxels with target class t and predicted class p.
+def _region_counts(conf, classes):
+    """(|o|, |t|, |o & t|, |o | t|) for the region {label in classes} of prediction o and target t."""
+    idx = list(classes)
+    o = conf[:, idx].sum()
+    t = conf[idx, :].sum()
+    both = conf[idx][:, idx].sum()
+    return o, t, both, o + t - both
+
+
+def dice_score(conf, classes, eps=1e-8):
+    """predict.py:386-389 for the region `classes`: (2|o&t| + eps) / (|o| + |t| + eps)."""
+    o, t, both, _ = _region_counts(conf, classes)
+    return float((2 * both + eps) / (o + t + eps))
+
+
+def mIOU(conf, classes, eps=1e-8):
+    """predict.py:296-299 for the region `classes`."""
+    _, _, both, union = _region_counts(conf, classes)
+    return float((both + eps) / (union + eps))
+
+
+def softmax_output_dice(conf):
+    """predict.py:401-416 (BraTS): whole = labels > 0, core = {1, 3}, active = {3}."""
+    k = conf.shape[0]
+    return [dice_score(conf, range(1, k)), dice_score(conf, (1, 3)), dice_score(conf, (3,))]
+
+
+def softmax_output_litsdice(conf):
+    """predict.py:390-399 (LiTS): liver = {1, 2}, tumor = {2}."""
+    return [dice_score(conf, (1, 2)), dice_score(conf, (2,))]
+
+
+def evaluate_volume(out, target, num_classes, n_thr=0):
+    """Counts behind val()/test() for one predict_volume() result, reduced on the device, ONE host copy of
+    K*K + 8*n_thr + 3 numbers instead of the volumes -> dict(conf, ucount, mean_u, mean_conf, mean_confe)."""
+    import numpy as np
+    from . import ops
+    pred = out["pred"].reshape(-1)
+    r = ops.eval_counts(pred, target.reshape(-1).contiguous(), num_classes,
+                        out["umask"].reshape(-1) if n_thr else None, n_thr,
+                        out["u"].reshape(-1) if out.get("u") is not None else None)
+    if int(r["bad"].item()):
+        raise ValueError("evaluate_volume: a label or prediction is outside [0, %d)" % num_classes)
+    nv = pred.numel()
+    res = dict(conf=r["conf"].cpu().numpy(), ucount=r["ucount"].cpu().numpy() if n_thr else None)
+    if r["sums"] is not None:
+        s = r["sums"].cpu().numpy()
+        res.update(mean_u=s[0] / nv, mean_conf=s[1] / nv, mean_confe=s[2] / nv)
+    return res

@@ -146,12 +146,13 @@ def predict_volume(model, x, dataset, thresholds=()):
 
 
 def dice_per_class(pred, target, num_classes):
-    """Foreground dice on device (the reference computes it with numpy after a D2H copy)."""
+    """Per-class foreground dice from ONE device-side confusion-count pass (csrc/evalmaps.hip); the reference
+    computes it with numpy after a D2H copy of both volumes."""
+    conf = ops.eval_counts(pred.reshape(-1).contiguous(), target.reshape(-1).contiguous(), num_classes)["conf"].cpu()
     out = []
     for k in range(1, num_classes):
-        p, t = pred == k, target == k
-        inter = (p & t).sum().double()
-        out.append(((2 * inter) / (p.sum() + t.sum()).clamp_min(1)).item())
+        inter, p, t = conf[k, k].item(), conf[:, k].sum().item(), conf[k, :].sum().item()
+        out.append(2.0 * inter / max(p + t, 1))
     return out
 
 

@@ -299,6 +299,22 @@ int devis_evid_infer(const void* logits, int64_t sN, int64_t sV, int64_t sK, int
  * when the evidence is consumed outside the fused loss. */
 int devis_softplus_bwd(const float* z, const float* g, float* dz, int64_t n, void* stream);
 
+/* ------------------------------------------------------- evaluation counts -- */
+/* One pass over device-resident prediction / target / uncertainty maps that yields every count the reference's
+ * val()/test() metrics are made of (it copies the volumes to the host and counts with numpy):
+ *   conf[t*K + p]   int64: voxels with target t, prediction p -> dice_score, mIOU, softmax_output_dice,
+ *                   softmax_output_litsdice (predict.py:296-300,386-420; trainUMIS.py:286-331) are ratios of its sums;
+ *   ucount[i*8 + c] int64: tp, tn, fp, fn, tpu, tnu, fpu, fnu of numpyfunctions.uncertainty() (:86-107) with
+ *                   prediction = pred > 0, target = target > 0, thresholded_uncertainty = bit i of umask
+ *                   (devis_evid_infer: u > thresholds[i], trainUMIS.py:521), i < n_thr <= 16;
+ *   sums[0..2]      fp64: sum u, sum (1-u), sum exp(-u) -> mean uncertainty / conf / confe (trainUMIS.py:541-548).
+ * pred uint8, target per target_dtype (devis_label_dtype), umask/ucount may be NULL with n_thr = 0, u/sums may
+ * both be NULL.  *bad_label (device int) is set to 1 if a label or prediction is outside [0, K). */
+size_t devis_eval_counts_workspace_bytes(int64_t NV);
+int devis_eval_counts(const uint8_t* pred, const void* target, int target_dtype, const uint16_t* umask, int n_thr,
+                      const float* u, int64_t NV, int K, int64_t* conf, int64_t* ucount, double* sums,
+                      int* bad_label, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- optimizer -- */
 /* One Adam step with coupled L2 weight decay over flat fp32 arrays of n elements (16-byte aligned), in place:
  * torch.optim.Adam(model.parameters(), lr, weight_decay=1e-5) as trainUMIS.py:1394 builds it and :261 steps

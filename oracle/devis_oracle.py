@@ -361,3 +361,60 @@ def poly_lr(init_lr: float, epoch: int, max_epoch: int, power: float = 0.9) -> f
     """adjust_learning_rate, trainUMIS.py:217-219."""
     import numpy as np
     return round(init_lr * np.power(1 - epoch / max_epoch, power), 8)
+
+
+# ---------------------------------------------------------------- evaluation counts (SURVEY.md §8(f)-3)
+def uncertainty_counts(prediction, target, thresholded_uncertainty):
+    """numpyfunctions.py:86-107 (mask=None): boolean arrays -> tp, tn, fp, fn, tpu, tnu, fpu, fnu."""
+    import numpy as np
+    tps = np.logical_and(target, prediction)
+    tns = np.logical_and(~target, ~prediction)
+    fps = np.logical_and(~target, prediction)
+    fns = np.logical_and(target, ~prediction)
+    tpu = np.logical_and(tps, thresholded_uncertainty).sum()
+    tnu = np.logical_and(tns, thresholded_uncertainty).sum()
+    fpu = np.logical_and(fps, thresholded_uncertainty).sum()
+    fnu = np.logical_and(fns, thresholded_uncertainty).sum()
+    return tps.sum(), tns.sum(), fps.sum(), fns.sum(), tpu, tnu, fpu, fnu
+
+
+def dice_score(o, t, eps=1e-8):
+    """predict.py:386-389."""
+    num = 2 * (o * t).sum() + eps
+    den = o.sum() + t.sum() + eps
+    return num / den
+
+
+def mIOU(o, t, eps=1e-8):
+    """predict.py:296-299."""
+    num = (o * t).sum() + eps
+    den = (o | t).sum() + eps
+    return num / den
+
+
+def softmax_output_dice(output, target):
+    """predict.py:401-416: BraTS whole / core / active."""
+    return [dice_score(output > 0, target > 0),
+            dice_score((output == 1) | (output == 3), (target == 1) | (target == 3)),
+            dice_score(output == 3, target == 3)]
+
+
+def softmax_output_litsdice(output, target):
+    """predict.py:390-399: LiTS liver / tumor."""
+    return [dice_score((output == 1) | (output == 2), (target == 1) | (target == 2)),
+            dice_score(output == 2, target == 2)]
+
+
+def eval_counts(pred, target, u, thresholds, classes: int):
+    """What devis_eval_counts returns, from numpy arrays: conf[t, p], ucount[i] = uncertainty_counts(pred > 0,
+    target > 0, u > thresholds[i]) (trainUMIS.py:521 thresholds), sums = (sum u, sum 1-u, sum exp(-u))."""
+    import numpy as np
+    pred = np.asarray(pred).reshape(-1).astype(np.int64)
+    target = np.asarray(target).reshape(-1).astype(np.int64)
+    conf = np.zeros((classes, classes), dtype=np.int64)
+    np.add.at(conf, (target, pred), 1)
+    u = np.asarray(u, dtype=np.float32).reshape(-1)
+    ucount = np.array([uncertainty_counts(pred > 0, target > 0, u > np.float32(t)) for t in thresholds], dtype=np.int64)
+    sums = np.array([u.astype(np.float64).sum(), (np.float32(1) - u).astype(np.float64).sum(),
+                     np.exp(-u).astype(np.float64).sum()])
+    return conf, ucount.reshape(len(thresholds), 8), sums

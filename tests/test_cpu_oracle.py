@@ -183,3 +183,35 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, "%s has no ctypes signature" % name
     assert lib.devis_version() >= 100
     assert lib.devis_evid_workspace_bytes(1, 8, 4) > 0       # pure host arithmetic, no GPU touched
+
+
+# ------------------------------------------------------------------ evaluation counts (§8(f)-3)
+def _evalmaps_case(golden, tag):
+    import numpy as np
+    g = golden("evalmaps")
+    shape, K = tuple(int(v) for v in g[tag + "_shape"]), int(g[tag + "_K"])
+    gen = torch.Generator().manual_seed(21)
+    target = torch.randint(0, K, shape, generator=gen)
+    pred = torch.where(torch.rand(shape, generator=gen) < 0.7, target, torch.randint(0, K, shape, generator=gen))
+    u = torch.rand(shape, generator=gen)
+    return g, K, pred, target, u.numpy().astype(np.float32)
+
+
+@pytest.mark.parametrize("tag", ["brats", "lits", "bin"])
+def test_eval_counts_oracle_matches_reference_goldens(golden, tag):
+    """oracle.eval_counts + the metric helpers reproduce what the reference's numpyfunctions.uncertainty /
+    predict.dice_score / mIOU / softmax_output_dice returned on the same seeded volumes (integers exact)."""
+    import numpy as np
+    from oracle import devis_oracle as O
+    from devis_amd import predict as P
+    g, K, pred, target, u = _evalmaps_case(golden, tag)
+    conf, ucount, sums = O.eval_counts(pred.numpy(), target.numpy(), u, O.UNCERTAINTY_THRESHOLDS, K)
+    assert np.array_equal(conf, g[tag + "_conf"]) and np.array_equal(ucount, g[tag + "_ucount"])
+    assert np.allclose(sums, g[tag + "_sums"], rtol=1e-12)
+    # the product's host helpers work from the confusion counts alone
+    assert abs(P.dice_score(conf, range(1, K)) - float(g[tag + "_fg_dice"])) < 1e-12
+    assert abs(P.mIOU(conf, range(1, K)) - float(g[tag + "_fg_miou"])) < 1e-12
+    if K == 4:
+        assert np.allclose(P.softmax_output_dice(conf), g[tag + "_dice3"], rtol=0, atol=1e-12)
+    if K == 3:
+        assert np.allclose(P.softmax_output_litsdice(conf), g[tag + "_dice2"], rtol=0, atol=1e-12)
