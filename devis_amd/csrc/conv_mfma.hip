@@ -327,6 +327,9 @@ int conv3_c16_march(const devis_conv_desc* d, const void* x, const void* w, cons
 int conv3_deep(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
                const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
 
+int conv3_c32_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
+                    const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
+
 static bool is_3x3x3(const devis_conv_desc* d) {
   return d->KD == 3 && d->KH == 3 && d->KW == 3 && d->PD == 1 && d->PH == 1 && d->PW == 1 && d->SD == d->SH && d->SH == d->SW;
 }
@@ -352,6 +355,8 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
     if (!no_deep && ci == co && (ci == 64 || ci == 128)) return conv3_deep(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
     if (ci == 16 && co == 16) return CONV3(16, 16, 8, 8, 16, 1);
     if (ci == 4 && co == 16 && !sc) return CONV3(16, 16, 8, 8, 16, 1);
+    static const bool no_march32 = getenv("DEVIS_NO_MARCH32") != nullptr;
+    if (!no_march32 && ci == 32 && co == 32) return conv3_c32_march(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
     if (ci == 32 && co == 32) return CONV3(32, 32, 4, 8, 16, 1, 2);
     if (ci == 64 && co == 64) return CONV3(64, 64, 4, 4, 16, 1);
     if (ci == 128 && co == 128) return CONV3(128, 32, 2, 4, 16, 1);
