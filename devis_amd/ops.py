@@ -23,8 +23,31 @@ def _p(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_stream_override = None     # raw stream handle that replaces torch's current stream (see stream_override)
+
+
 def _stream() -> int:
+    if _stream_override is not None:
+        return _stream_override
     return torch.cuda.current_stream().cuda_stream
+
+
+class stream_override:
+    """Launch the enclosed ops calls on `stream` (a torch.cuda.Stream) without switching torch's current stream:
+    cheaper than `with torch.cuda.stream(...)` for calls that allocate nothing (outputs and workspace given)."""
+
+    def __init__(self, stream):
+        self.handle = stream.cuda_stream
+
+    def __enter__(self):
+        global _stream_override
+        self.prev = _stream_override
+        _stream_override = self.handle
+
+    def __exit__(self, *exc):
+        global _stream_override
+        _stream_override = self.prev
+        return False
 
 
 def dt_code(dtype: torch.dtype) -> int:
@@ -183,15 +206,22 @@ class ConvGeom:
         self.k, self.s = tri(kernel), tri(stride)
         p = tuple(int(a) for a in pad)
         self.p = (0,) * (3 - len(p)) + p if len(p) < 3 else p
+        self._descs = {}
 
     def out_spatial(self, isp: Tuple[int, int, int]) -> Tuple[int, int, int]:
         return tuple((i + 2 * p - k) // s + 1 for i, k, s, p in zip(isp, self.k, self.s, self.p))
 
     def desc(self, n: int, isp, c1: int, c2: int, cout: int, dtype: torch.dtype) -> ConvDesc:
-        osp = self.out_spatial(isp)
-        return ConvDesc(n, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2], c1, c2, cout,
-                        self.k[0], self.k[1], self.k[2], self.s[0], self.s[1], self.s[2],
-                        self.p[0], self.p[1], self.p[2], dt_code(dtype))
+        """The C descriptor of this layer at this shape (cached: callers treat it as read-only)."""
+        key = (n, tuple(isp), c1, c2, cout, dtype)
+        d = self._descs.get(key)
+        if d is None:
+            osp = self.out_spatial(isp)
+            d = ConvDesc(n, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2], c1, c2, cout,
+                         self.k[0], self.k[1], self.k[2], self.s[0], self.s[1], self.s[2],
+                         self.p[0], self.p[1], self.p[2], dt_code(dtype))
+            self._descs[key] = d
+        return d
 
 
 def _out_shape(x: Tensor, osp, cout: int):

@@ -169,18 +169,20 @@ class _Run:
     def _wg(self, fn, *args, **kw):
         """Run a weight-gradient call.  Nothing on backward's critical path (dgrad -> norm backward -> dgrad ...)
         reads a weight gradient, so with a side stream they are launched there, behind an event that marks their
-        inputs ready, and fill the CUs the small deep-layer kernels of the main stream leave idle.  Inputs are
-        recorded on the side stream so the caching allocator does not hand their memory out while it still reads."""
+        inputs ready, and fill the CUs the small deep-layer kernels of the main stream leave idle.  The calls
+        allocate nothing (gradient views and workspace are given), so the stream is handed to the kernels
+        directly; their inputs are kept referenced until backward has joined the side stream, so the caching
+        allocator cannot hand their memory out while it is still being read."""
         side = self.side
         if side is None:
             return fn(*args, **kw)
-        main = torch.cuda.current_stream()
-        side.wait_event(main.record_event())
-        with torch.cuda.stream(side):
+        ev = self._events[self._nev % len(self._events)]
+        self._nev += 1
+        ev.record()                               # on the main (current) stream: inputs are ready behind it
+        side.wait_event(ev)
+        with ops.stream_override(side):
             out = fn(*args, slot="ws_side", **kw)
-        for t in args:
-            if isinstance(t, Tensor):
-                t.record_stream(side)
+        self._keep.append(args)
         return out
 
     def _next_norm(self):
@@ -256,7 +258,9 @@ class _Run:
         t = self.tape
         pop = t.pop
         self.side = _side_stream(dlogits.device)
+        self._keep, self._nev = [], 0
         if self.side is not None:
+            self._events = _side_events(dlogits.device)
             for v in self.G.values():             # views of one flat buffer: recording one records the block
                 v.record_stream(self.side)
                 break
@@ -278,6 +282,7 @@ class _Run:
         d = self._conv_bwd(pop(), d, need_dx)                    # InitConv
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        self._keep = []                           # freed behind the join, on the stream that allocated them
         self._bucket_done(2)
         return d
 
@@ -300,6 +305,19 @@ def _side_stream(device):
     if s is None:
         s = _side_streams[device.index] = torch.cuda.Stream(device)
     return s
+
+
+_side_event_pool: Dict[int, list] = {}
+
+
+def _side_events(device):
+    """Reusable events that order the side stream behind the main one (one per weight-gradient call of a step,
+    more than a backward ever has in flight)."""
+    ev = _side_event_pool.get(device.index)
+    if ev is None:
+        with torch.cuda.device(device):
+            ev = _side_event_pool[device.index] = [torch.cuda.Event() for _ in range(64)]
+    return ev
 
 
 class _Unet3dFn(torch.autograd.Function):
