@@ -102,6 +102,13 @@ SIGNATURES = {
     "devis_evid_crit_fwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     "devis_evid_crit_bwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devis_evid_infer": (_I, [_P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "devis_att_chunks": (_I64, [_I64]),
+    "devis_att_psi_bwd_chunks": (_I64, [_I64, _I64, _I]),
+    "devis_att_psi_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
+    "devis_att_gate_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P]),
+    "devis_att_gate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I64, _I64, _I64, _I, _P]),
+    "devis_att_psi_bwd_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
+    "devis_att_psi_bwd": (_I, [_P] * 12 + [_I64, _I64, _I64, _I, _P, _P, _P, _SZ, _P, _P, _P, _SZ, _P]),
     "devis_eval_counts_workspace_bytes": (_SZ, [_I64]),
     "devis_eval_counts": (_I, [_P, _P, _I, _P, _I, _P, _I64, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "devis_adam_step": (_I, [_P, _P, _P, _P, _I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I64, _P]),

@@ -476,25 +476,112 @@ def affine_act(x: Tensor, scale: Tensor, shift: Tensor, residual: Optional[Tenso
     return y
 
 
-def norm_relu_bwd(dy: Tensor, x: Tensor, scale: Tensor, shift: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
-                  groups: int, bn: bool, extra: Optional[Tensor] = None, out=None, partials=None):
-    """Backward of relu(norm(x)) -> (dx (+extra), dgamma, dbeta).  `out` = (dgamma, dbeta) buffers to fill;
-    `partials` = (buffer, chunks) when the kernel that produced dy already left the per-chunk moments."""
-    _need_cuda(dy, x, extra)
-    n, v, c = _nvc(x)
-    ws, chunks = partials if partials is not None else _moment_partials(x, dy, scale, shift)
-    f = dict(dtype=torch.float32, device=x.device)
+_gate_cache = {}
+
+
+def _open_gate(n: int, c: int, device):
+    """(scale, shift) = (0, 1): makes the ReLU mask [scale*x + shift > 0] of the norm-backward kernels all ones,
+    i.e. the backward of a norm WITHOUT activation (the attention gate's BatchNorms)."""
+    key = (n, c, device.index)
+    g = _gate_cache.get(key)
+    if g is None:
+        g = _gate_cache[key] = (torch.zeros((n, c), dtype=torch.float32, device=device),
+                                torch.ones((n, c), dtype=torch.float32, device=device))
+    return g
+
+
+def norm_bwd_coeffs(partials, n: int, v: int, c: int, gamma: Tensor, mean: Tensor, rstd: Tensor, groups: int,
+                    bn: bool, out=None):
+    """Per-chunk moments {sum dy', sum dy'*x} -> (coef[3, n, c] = cA, cB, cC of dx = cA*dy' + cB*x + cC, dgamma, dbeta)."""
+    ws, chunks = partials
+    f = dict(dtype=torch.float32, device=gamma.device)
     coef = torch.empty((3, n, c), **f)
     dgamma, dbeta = out if out is not None else (torch.empty((c,), **f), torch.empty((c,), **f))
     _check_out(dgamma, dbeta)
-    lib = _lib.load()
-    check(lib.devis_norm_bwd_finalize_partials(_p(ws), chunks, n, v, c, groups, int(bn), _p(gamma), _p(mean), _p(rstd),
-                                               _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(dgamma), _p(dbeta), _stream()),
-          "norm_bwd_finalize_partials")
+    check(_lib.load().devis_norm_bwd_finalize_partials(_p(ws), chunks, n, v, c, groups, int(bn), _p(gamma), _p(mean),
+                                                       _p(rstd), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(dgamma),
+                                                       _p(dbeta), _stream()), "norm_bwd_finalize_partials")
+    return coef, dgamma, dbeta
+
+
+def norm_relu_bwd(dy: Tensor, x: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], gamma: Tensor, mean: Tensor,
+                  rstd: Tensor, groups: int, bn: bool, extra: Optional[Tensor] = None, out=None, partials=None,
+                  relu: bool = True):
+    """Backward of relu(norm(x)) -> (dx (+extra), dgamma, dbeta).  `out` = (dgamma, dbeta) buffers to fill;
+    `partials` = (buffer, chunks) when the kernel that produced dy already left the per-chunk moments;
+    relu=False: backward of the bare norm (scale / shift are not needed)."""
+    _need_cuda(dy, x, extra)
+    n, v, c = _nvc(x)
+    if not relu:
+        scale, shift = _open_gate(n, c, x.device)
+    if partials is None:
+        partials = _moment_partials(x, dy, scale, shift)
+    coef, dgamma, dbeta = norm_bwd_coeffs(partials, n, v, c, gamma, mean, rstd, groups, bn, out)
     dx = torch.empty_like(x)
-    check(lib.devis_norm_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(coef[0]), _p(coef[1]), _p(coef[2]),
-                                   _p(extra), _p(dx), n, v, c, dt_code(x.dtype), _stream()), "norm_bwd_apply")
+    check(_lib.load().devis_norm_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                           _p(extra), _p(dx), n, v, c, dt_code(x.dtype), _stream()), "norm_bwd_apply")
     return dx, dgamma, dbeta
+
+
+# ---------------------------------------------------------- attention gate
+def att_psi_fwd(g1: Tensor, x1: Tensor, st_g, st_x, w_psi: Tensor, b_psi: Tensor):
+    """-> (s fp32 [N, *spatial, 1], (moment partials of s, chunks)).  st_g / st_x = BatchNorm coefficients of g1 / x1."""
+    _need_cuda(g1, x1, w_psi, b_psi)
+    if g1.shape != x1.shape or g1.dtype != x1.dtype:
+        raise _lib.DevisError("attention gate: g1 and x1 must match")
+    n, v, c = _nvc(g1)
+    lib = _lib.load()
+    chunks = lib.devis_att_chunks(v)
+    s = torch.empty(tuple(g1.shape[:-1]) + (1,), dtype=torch.float32, device=g1.device)
+    part = torch.empty((n, chunks, 1, 2), dtype=torch.float64, device=g1.device)
+    check(lib.devis_att_psi_fwd(_p(g1), _p(x1), _p(st_g[0]), _p(st_g[1]), _p(st_x[0]), _p(st_x[1]), _p(w_psi), _p(b_psi),
+                                n, v, c, dt_code(g1.dtype), _p(s), _p(part), part.numel() * 8, _stream()), "att_psi_fwd")
+    return s, (part, chunks)
+
+
+def att_gate_fwd(skip: Tensor, s: Tensor, st_p) -> Tensor:
+    _need_cuda(skip, s)
+    n, v, c = _nvc(skip)
+    out = torch.empty_like(skip)
+    check(_lib.load().devis_att_gate_fwd(_p(skip), _p(s), _p(st_p[0]), _p(st_p[1]), _p(out), n, v, c,
+                                         dt_code(skip.dtype), _stream()), "att_gate_fwd")
+    return out
+
+
+def att_gate_bwd(dout: Tensor, skip: Tensor, s: Tensor, st_p):
+    """-> (dskip = dout * p, dz fp32 like s, (partials {sum dz, sum dz*s}, chunks))"""
+    _need_cuda(dout, skip, s)
+    n, v, c = _nvc(skip)
+    lib = _lib.load()
+    chunks = lib.devis_att_chunks(v)
+    dskip = torch.empty_like(skip)
+    dz = torch.empty_like(s)
+    part = torch.empty((n, chunks, 1, 2), dtype=torch.float64, device=skip.device)
+    check(lib.devis_att_gate_bwd(_p(dout), _p(skip), _p(s), _p(st_p[0]), _p(st_p[1]), _p(dskip), _p(dz), _p(part),
+                                 part.numel() * 8, n, v, c, dt_code(skip.dtype), _stream()), "att_gate_bwd")
+    return dskip, dz, (part, chunks)
+
+
+def att_psi_bwd(dz: Tensor, s: Tensor, coef_p: Tensor, g1: Tensor, x1: Tensor, st_g, st_x, w_psi: Tensor, out):
+    """-> (dpre like g1, partials_g, partials_x): gradient w.r.t. both BatchNorm outputs and their backward moments;
+    fills out = (dw_psi, db_psi)."""
+    _need_cuda(dz, s, g1, x1, w_psi)
+    n, v, c = _nvc(g1)
+    lib = _lib.load()
+    chunks = lib.devis_att_psi_bwd_chunks(v, c, dt_code(g1.dtype))
+    if chunks <= 0:
+        raise _lib.DevisError("attention gate: unsupported F_int = %d" % c)
+    dpre = torch.empty_like(g1)
+    mom = torch.empty((2, n, chunks, c, 2), dtype=torch.float64, device=g1.device)
+    dw, db = out
+    _check_out(dw, db)
+    nb = lib.devis_att_psi_bwd_workspace_bytes(n, v, c, dt_code(g1.dtype))
+    ws = workspace(nb, g1.device)
+    check(lib.devis_att_psi_bwd(_p(dz), _p(s), _p(coef_p[0]), _p(coef_p[1]), _p(coef_p[2]), _p(g1), _p(x1),
+                                _p(st_g[0]), _p(st_g[1]), _p(st_x[0]), _p(st_x[1]), _p(w_psi), n, v, c,
+                                dt_code(g1.dtype), _p(dpre), _p(mom[0]), _p(mom[1]), mom[0].numel() * 8, _p(dw), _p(db),
+                                _p(ws), nb, _stream()), "att_psi_bwd")
+    return dpre, (mom[0], chunks), (mom[1], chunks)
 
 
 def add(a: Tensor, b: Tensor) -> Tensor:

@@ -6,7 +6,7 @@ kernels of this package.  Deviations from the reference, all documented in DESIG
   * ``self.backbone.cuda()`` (TrustworthySeg.py:116) becomes ``.to(current cuda device)``;
   * the ISIC branch, which raises NameError in the reference (TrustworthySeg.py:51 uses the
     undefined names ``model``/``classes``), selects ``Unet2D(3, num_classes)`` for model 'U';
-  * backbones outside SURVEY.md §8 (AU, V, ResU) raise NameError like an unknown model does.
+  * backbones outside SURVEY.md §8 (V, ResU, the 2-D AU) raise NameError like an unknown model does.
 """
 from __future__ import annotations
 
@@ -18,6 +18,7 @@ from .criterions import evidential_head_loss
 from .predict import tailor_and_concat
 from .unet2d import Unet2D, Unet2DDRIVE
 from .unet3d import Unet
+from .attunet3d import AttUnet
 
 
 class TMSU(nn.Module):
@@ -32,9 +33,13 @@ class TMSU(nn.Module):
         if dataset == 'BraTS':
             if model_name == 'U' and input_modality == 'four':
                 backbone = Unet(in_channels=4, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
+            elif model_name == 'AU' and input_modality == 'four':            # TrustworthySeg.py:40-41
+                backbone = AttUnet(in_channels=4, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
         elif dataset == 'LiTS':
             if model_name == 'U':
                 backbone = Unet(in_channels=1, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
+            elif model_name == 'AU':                                         # TrustworthySeg.py:65
+                backbone = AttUnet(in_channels=1, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
         elif dataset == 'ISIC':
             if model_name == 'U':
                 backbone = Unet2D(3, num_classes, compute_dtype=dtype)

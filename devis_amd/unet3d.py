@@ -257,13 +257,7 @@ class _Run:
         """Mirror of forward(); returns d(input) (or None) and fills self.grads."""
         t = self.tape
         pop = t.pop
-        self.side = _side_stream(dlogits.device)
-        self._keep, self._nev = [], 0
-        if self.side is not None:
-            self._events = _side_events(dlogits.device)
-            for v in self.G.values():             # views of one flat buffer: recording one records the block
-                v.record_stream(self.side)
-                break
+        self._begin_backward(dlogits.device)
         e = pop()
         d, pt = self._conv_bwd(e, dlogits, norm=self._next_norm())    # endconv (+ moments for DeBlock2.bn2)
         d = self._de_bwd(pop(), d, pt); d, ds1, pt = self._up_bwd(pop(), d)   # DeBlock2, DeUpCat2
@@ -280,11 +274,23 @@ class _Run:
         d = self._conv_bwd(pop(), d, skip=ds1)               # EnDown1
         d = self._en_bwd(pop(), d)                               # EnBlock1
         d = self._conv_bwd(pop(), d, need_dx)                    # InitConv
+        self._end_backward()
+        self._bucket_done(2)
+        return d
+
+    def _begin_backward(self, device):
+        self.side = _side_stream(device)
+        self._keep, self._nev = [], 0
+        if self.side is not None:
+            self._events = _side_events(device)
+            for v in self.G.values():             # views of one flat buffer: recording one records the block
+                v.record_stream(self.side)
+                break
+
+    def _end_backward(self):
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         self._keep = []                           # freed behind the join, on the stream that allocated them
-        self._bucket_done(2)
-        return d
 
     def _bucket_done(self, i):
         if self.sync is not None:
@@ -328,7 +334,7 @@ class _Unet3dFn(torch.autograd.Function):
         names = model._param_names
         P = dict(zip(names, params))
         taping = any(ctx.needs_input_grad)
-        run = _Run(P, dict(model.named_buffers()), model.compute_dtype, model.training, taping, model._packed(P))
+        run = model._run_cls(P, dict(model.named_buffers()), model.compute_dtype, model.training, taping, model._packed(P))
         logits = run.forward(ops.to_channels_last(x, model.compute_dtype))
         ctx.run, ctx.names, ctx.model = run, names, model
         ctx.need_dx = ctx.needs_input_grad[1]
@@ -394,19 +400,26 @@ class Unet(nn.Module):
         self.DeUpCat2 = _DeUpCat(b * 2, b)
         self.DeBlock2 = _DeBlock(b)
         self.endconv = nn.Conv3d(b, num_classes, kernel_size=1)
+        self._finish_init(compute_dtype, num_classes)
+
+    _run_cls = None       # set below: the schedule class that executes this backbone
+
+    def _finish_init(self, compute_dtype, num_classes):
+        """Bookkeeping shared by the 3-D backbones: parameter order, conv modules to pack, flat gradient layout."""
         self.compute_dtype = compute_dtype
         self.num_classes = num_classes
         self._param_names = [n for n, _ in self.named_parameters()]
         self._conv_modules = [(n + ".weight", m) for n, m in self.named_modules()
                               if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d))]
         self._packer = None
-        # gradient layout: reverse registration order = the order backward completes the modules
+        # gradient layout: reverse registration order ~ the order backward completes the modules.  Bucket 0 ends
+        # where the decoder does (first EnBlock4_4 parameter), bucket 1 covers the EnBlock4_* stage.
         off, layout, bounds = 0, {}, []
         plist = list(self.named_parameters())
         for n, p_ in reversed(plist):
             if n.startswith("EnBlock4_4.") and len(bounds) == 0:
-                bounds.append(off)                   # end of bucket 0: endconv ... DeUpCat4
-            if n.startswith("EnDown3.") and len(bounds) == 1:
+                bounds.append(off)                   # end of bucket 0: endconv ... first decoder module
+            if len(bounds) == 1 and off > bounds[0] and not n.startswith("EnBlock4_"):
                 bounds.append(off)                   # end of bucket 1: EnBlock4_*
             layout[n] = (off, p_.numel(), tuple(p_.shape))
             off += p_.numel()
@@ -444,3 +457,6 @@ class Unet(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         return _FromChannelsLast.apply(self.forward_channels_last(x))
+
+
+Unet._run_cls = _Run

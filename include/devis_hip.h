@@ -299,6 +299,36 @@ int devis_evid_infer(const void* logits, int64_t sN, int64_t sV, int64_t sK, int
  * when the evidence is consumed outside the fused loss. */
 int devis_softplus_bwd(const float* z, const float* g, float* dz, int64_t n, void* stream);
 
+/* ---------------------------------------------------------- attention gate -- */
+/* Attention_block of the 3-D attention U-Net (UNet3DZoo.py:69-100) behind its 1x1 convs W_g / W_x:
+ *   a = relu(BN_g(g1) + BN_x(x1));  s = psi_conv(a) (one channel, fp32 [N][V]);  out = skip * sigmoid(BN_psi(s)).
+ * The three BatchNorms enter as per-(n,c) affine coefficients (devis_bn_finalize*), their statistics leave as
+ * partial[n][chunk][C][2] fp64 for devis_bn_finalize_partials / devis_norm_bwd_finalize_partials:
+ *   devis_att_psi_fwd   g1, x1 [N][V][C] -> s and the moments {sum s, sum s^2}          (chunks = devis_att_chunks(V), C = 1)
+ *   devis_att_gate_fwd  skip [N][V][Cs], s, scale/shift of BN_psi [N] -> out
+ *   devis_att_gate_bwd  dout -> dskip = dout*p, dz = p(1-p) sum_c dout*skip (fp32), moments {sum dz, sum dz*s}
+ *   devis_att_psi_bwd   dz, s, BN_psi backward coefficients cA/cB/cC [N] -> dpre = d(BN_g out) = d(BN_x out)
+ *                       [N][V][C], the BatchNorm-backward moments of both branches (chunks =
+ *                       devis_att_psi_bwd_chunks), and the psi conv's weight / bias gradients (fp32 [C], [1]).
+ * C = F_int <= 64 with C/8 (bf16) or C/4 (fp32) a power of two <= 16. */
+int64_t devis_att_chunks(int64_t V);
+int64_t devis_att_psi_bwd_chunks(int64_t V, int64_t C, int dtype);
+int devis_att_psi_fwd(const void* g1, const void* x1, const float* scale_g, const float* shift_g,
+                      const float* scale_x, const float* shift_x, const float* w_psi, const float* b_psi,
+                      int64_t N, int64_t V, int64_t C, int dtype, float* s, double* partials,
+                      size_t partials_bytes, void* stream);
+int devis_att_gate_fwd(const void* skip, const float* s, const float* scale_psi, const float* shift_psi, void* out,
+                       int64_t N, int64_t V, int64_t C, int dtype, void* stream);
+int devis_att_gate_bwd(const void* dout, const void* skip, const float* s, const float* scale_psi,
+                       const float* shift_psi, void* dskip, float* dz, double* partials, size_t partials_bytes,
+                       int64_t N, int64_t V, int64_t C, int dtype, void* stream);
+size_t devis_att_psi_bwd_workspace_bytes(int64_t N, int64_t V, int64_t C, int dtype);
+int devis_att_psi_bwd(const float* dz, const float* s, const float* cA, const float* cB, const float* cC,
+                      const void* g1, const void* x1, const float* scale_g, const float* shift_g,
+                      const float* scale_x, const float* shift_x, const float* w_psi, int64_t N, int64_t V,
+                      int64_t C, int dtype, void* dpre, double* moments_g, double* moments_x, size_t moments_bytes,
+                      float* dw_psi, float* db_psi, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------- evaluation counts -- */
 /* One pass over device-resident prediction / target / uncertainty maps that yields every count the reference's
  * val()/test() metrics are made of (it copies the volumes to the host and counts with numpy):

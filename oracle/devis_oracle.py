@@ -92,6 +92,65 @@ def unet3d_forward(sd: StateDict, x: Tensor, training: bool = True) -> Tensor:
 
 
 # ----------------------------------------------------------------------------
+# 3D attention U-Net  (models/lib/UNet3DZoo.py:69-115,132-143,167-241)   SURVEY.md §8(f)-1
+# ----------------------------------------------------------------------------
+
+def _bn(sd: StateDict, key: str, x: Tensor, training: bool) -> Tensor:
+    # nn.BatchNorm3d without activation (Attention_block, UNet3DZoo.py:72-86)
+    if training:
+        sd[key + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, sd[key + ".running_mean"], sd[key + ".running_var"],
+                        sd[key + ".weight"], sd[key + ".bias"], training, 0.1, 1e-5)
+
+
+def _attention_block(sd: StateDict, name: str, g: Tensor, x: Tensor, training: bool) -> Tensor:
+    # Attention_block.forward, UNet3DZoo.py:90-100
+    g1 = _bn(sd, name + ".W_g.1", _conv(sd, name + ".W_g.0", g, pad=0), training)
+    x1 = _bn(sd, name + ".W_x.1", _conv(sd, name + ".W_x.0", x, pad=0), training)
+    psi = F.relu(g1 + x1)
+    psi = torch.sigmoid(_bn(sd, name + ".psi.1", _conv(sd, name + ".psi.0", psi, pad=0), training))
+    return x * psi
+
+
+def _de_up(sd: StateDict, name: str, x: Tensor) -> Tensor:
+    # DeUp.forward, UNet3DZoo.py:139-143: 1x1 -> ConvT k2 s2 -> 1x1
+    h = _conv(sd, name + ".conv1", x, pad=0)
+    h = F.conv_transpose3d(h, sd[name + ".conv2.weight"], sd[name + ".conv2.bias"], stride=2)
+    return _conv(sd, name + ".conv3", h, pad=0)
+
+
+def _de_cat(sd: StateDict, name: str, x: Tensor, prev: Tensor) -> Tensor:
+    # De_Cat.forward, UNet3DZoo.py:109-115: cat((x, prev)) -> 1x1
+    return _conv(sd, name + ".conv1", torch.cat((x, prev), dim=1), pad=0)
+
+
+def attunet3d_forward(sd: StateDict, x: Tensor, training: bool = True) -> Tensor:
+    """AttUnet.forward, UNet3DZoo.py:206-241.  Note the argument order of the three De_Cat calls: level 4
+    concatenates (gated skip, upsampled), levels 3 and 2 (upsampled, gated skip) (:227, :232, :237)."""
+    h = _conv(sd, "InitConv.conv", x)
+    s1 = _en_block(sd, "EnBlock1", h)
+    h = _conv(sd, "EnDown1.conv", s1, stride=2)
+    h = _en_block(sd, "EnBlock2_1", h)
+    s2 = _en_block(sd, "EnBlock2_2", h)
+    h = _conv(sd, "EnDown2.conv", s2, stride=2)
+    h = _en_block(sd, "EnBlock3_1", h)
+    s3 = _en_block(sd, "EnBlock3_2", h)
+    h = _conv(sd, "EnDown3.conv", s3, stride=2)
+    for i in (1, 2, 3, 4):
+        h = _en_block(sd, "EnBlock4_%d" % i, h)
+    y4 = _de_up(sd, "DeUp4", h)
+    a3 = _attention_block(sd, "Att4", y4, s3, training)
+    y4 = _de_block(sd, "DeBlock4", _de_cat(sd, "DeUpCat4", a3, y4), training)
+    y3 = _de_up(sd, "DeUp3", y4)
+    a2 = _attention_block(sd, "Att3", y3, s2, training)
+    y3 = _de_block(sd, "DeBlock3", _de_cat(sd, "DeUpCat3", y3, a2), training)
+    y2 = _de_up(sd, "DeUp2", y3)
+    a1 = _attention_block(sd, "Att2", y2, s1, training)
+    y2 = _de_block(sd, "DeBlock2", _de_cat(sd, "DeUpCat2", y2, a1), training)
+    return _conv(sd, "endconv", y2, pad=0)
+
+
+# ----------------------------------------------------------------------------
 # 2D U-Net  (models/lib/UNet2DZoo.py:107-259)
 # ----------------------------------------------------------------------------
 

@@ -1,0 +1,109 @@
+"""GPU parity: 3-D attention U-Net + fused evidential head/loss against the goldens the real
+reference produced through TMSU(model_name='AU') (tests/golden/attunet.npz) and against the CPU oracle live.
+Bars as for the Unet: fp32 loss 1e-5 rel, evidence / logits 2e-5, gradients tests/util.py GRAD_*_TOL;
+bf16 loss 1e-3, evidence 2e-2."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import GRAD_L2_TOL, GRAD_MAX_TOL, brats_args, l2_rel_err, rel_err, sd_hash
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(seed, dtype):
+    from devis_amd import TMSU
+    torch.manual_seed(seed)
+    m = TMSU(brats_args(model_name='AU', compute_dtype=dtype))
+    m.train()
+    return m
+
+
+def _inputs(seed, shape):
+    g = torch.Generator().manual_seed(2000 + seed)
+    x = torch.randn(shape, generator=g)
+    y = torch.randint(0, 4, (shape[0],) + tuple(shape[2:]), generator=g)
+    return x, y
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_attunet_train_step_fp32_vs_golden(golden, seed):
+    G = golden("attunet")
+    pre = "s%d_" % seed
+    shape = tuple(int(v) for v in G[pre + "shape"])
+    m = _make(seed, torch.float32)
+    sd0 = {k: v.cpu() for k, v in m.backbone.state_dict().items()}
+    assert list(sd0.keys()) == [str(k) for k in G[pre + "keys"]], "state_dict keys / order differ from the reference's"
+    assert sd_hash(sd0) == str(G[pre + "sd_hash"]), "seeded init differs from the reference's"
+    x, y = _inputs(seed, shape)
+    ev, loss = m(x.cuda(), y.cuda(), 25, 'train', 'BraTS')
+    loss.requires_grad_(True).backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(G[pre + "loss"])) < 1e-5 * abs(float(G[pre + "loss"])) + 1e-6
+    assert rel_err(ev.detach()[..., ::2], G[pre + "evidence"]) < 2e-5
+    params = dict(m.backbone.named_parameters())
+    for key in G.files:
+        if not key.startswith(pre + "grad_"):
+            continue
+        k = key[len(pre + "grad_"):]
+        g = params[k].grad
+        g = g.reshape(-1)[::37] if g.numel() > 20000 else g
+        ref = G[key]
+        if k.endswith("W_g.0.bias") or k.endswith("W_x.0.bias") or k.endswith("psi.0.bias"):
+            continue                      # bias in front of a BatchNorm: zero true gradient, rounding noise only
+        if l2_rel_err(g, ref) < GRAD_L2_TOL and rel_err(g, ref) < GRAD_MAX_TOL:
+            continue
+        # sums with heavy cancellation (the gate's BatchNorm(1) scale / shift, psi weights): the reference's own
+        # fp32 result is up to 0.5 % off the fp64 value of the same step; accept being at least as close to fp64
+        g64 = G[pre + "grad64_" + k]
+        assert l2_rel_err(g, g64) <= max(2 * l2_rel_err(ref, g64), 1e-4), (k, l2_rel_err(g, ref), l2_rel_err(g, g64))
+    norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
+    ref = G[pre + "gradnorm_all"]
+    assert np.all(np.abs(norms - ref) <= GRAD_L2_TOL * ref + 1e-6 * ref.max()), np.max(np.abs(norms - ref) / (ref + 1e-30))
+    sd = m.backbone.state_dict()
+    for k in ("Att4.W_g.1.running_mean", "Att4.psi.1.running_var", "Att2.W_x.1.running_var", "DeBlock2.bn2.running_mean"):
+        assert rel_err(sd[k], G[pre + "buf_" + k]) < 1e-5, k
+    assert int(sd["Att3.psi.1.num_batches_tracked"]) == 1
+    m.eval()
+    with torch.no_grad():
+        lg = m.backbone(x.cuda())
+    assert rel_err(lg[..., ::2], G[pre + "eval_logits"]) < 2e-5
+
+
+def test_attunet_train_step_bf16_vs_golden(golden):
+    G = golden("attunet")
+    pre = "s0_"
+    shape = tuple(int(v) for v in G[pre + "shape"])
+    m = _make(0, torch.bfloat16)
+    x, y = _inputs(0, shape)
+    ev, loss = m(x.cuda(), y.cuda(), 25, 'train', 'BraTS')
+    loss.backward()
+    assert abs(loss.item() - float(G[pre + "loss"])) < 1e-3
+    assert rel_err(ev.detach()[..., ::2], G[pre + "evidence"]) < 2e-2
+    params = dict(m.backbone.named_parameters())
+    norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
+    ref = G[pre + "gradnorm_all"]
+    assert np.all(np.abs(norms - ref) <= 0.08 * ref + 1e-3 * ref.max()), np.max(np.abs(norms - ref) / (ref + 1e-12))
+
+
+def test_attunet_matches_oracle_live_with_input_gradient():
+    """LiTS-style single-channel input, batch 2, odd-shaped volume, fp32: logits and d(loss)/d(input)."""
+    from oracle import devis_oracle as O
+    from devis_amd import AttUnet
+    torch.manual_seed(5)
+    net = AttUnet(1, 16, 3, compute_dtype=torch.float32)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.cuda().train()
+    g = torch.Generator().manual_seed(79)
+    x = torch.randn((2, 1, 8, 24, 16), generator=g)
+    wgt = torch.randn((2, 3, 8, 24, 16), generator=g)
+    xg = x.clone().cuda().requires_grad_(True)
+    out = net(xg)
+    (out * wgt.cuda()).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    ref = O.attunet3d_forward(sd, xr, True)
+    (ref * wgt).sum().backward()
+    assert rel_err(out.detach(), ref.detach()) < 2e-5
+    assert l2_rel_err(xg.grad, xr.grad) < GRAD_L2_TOL
+    for k in ("Att4.psi.1.running_var", "Att2.W_g.1.running_mean"):
+        assert rel_err(net.state_dict()[k], sd[k]) < 1e-5
