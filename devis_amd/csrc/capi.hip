@@ -19,6 +19,9 @@ int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void
 int conv1_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const void*, void*, hipStream_t);
 int conv1_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, const StatsArgs*, int64_t*,
                      hipStream_t);
+// head1x1.hip: the 16 -> 4 endconv
+int head_fwd(const devis_conv_desc*, const void*, const void*, const float*, const void*, void*, hipStream_t);
+int head_dgrad(const devis_conv_desc*, const void*, const void*, const void*, void*, const StatsArgs*, int64_t*, hipStream_t);
 int conv3s2_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
 size_t conv1_wgrad_mfma_workspace(const devis_conv_desc*);
 int conv1_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, float*, float*, void*, size_t, hipStream_t);
@@ -69,6 +72,8 @@ int64_t devis_conv_stats_chunks(const devis_conv_desc* d, int dgrad, int mode, i
   if (dgrad) {
     if (has_prologue) return 0;
     rc = conv_dgrad_mfma(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph), nullptr, &st, &chunks, nullptr);
+    if (rc == DEVIS_ERR_UNSUPPORTED)
+      rc = head_dgrad(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph), &st, &chunks, nullptr);
     if (rc == DEVIS_ERR_UNSUPPORTED && d->C2 == 0)      // 1x1 layers: the gather-GEMM kernel
       rc = conv1_dgrad_mfma(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph), nullptr, &st, &chunks, nullptr);
   } else {
@@ -91,6 +96,8 @@ int devis_conv_fwd_stats(const devis_conv_desc* d, const void* x1, const void* x
   rc = conv_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;      // statistics only come from the MFMA kernels
   if (!in_scale) {
+    rc = head_fwd(d, x1, w, bias, residual, y, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
     rc = conv1_fwd_mfma(d, x1, x2, w, bias, residual, y, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
@@ -112,6 +119,8 @@ int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void*
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   rc = conv_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = head_dgrad(d, dy, w, residual, dx1, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = conv1_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;     // statistics only come from the MFMA kernels
