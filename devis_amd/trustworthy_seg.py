@@ -6,7 +6,7 @@ kernels of this package.  Deviations from the reference, all documented in DESIG
   * ``self.backbone.cuda()`` (TrustworthySeg.py:116) becomes ``.to(current cuda device)``;
   * the ISIC branch, which raises NameError in the reference (TrustworthySeg.py:51 uses the
     undefined names ``model``/``classes``), selects ``Unet2D(3, num_classes)`` for model 'U';
-  * backbones outside SURVEY.md §8 (V, ResU, the 2-D AU) raise NameError like an unknown model does.
+  * backbones outside SURVEY.md §8 (ResU, the 2-D AU and V) raise NameError like an unknown model does.
 """
 from __future__ import annotations
 
@@ -19,6 +19,7 @@ from .predict import tailor_and_concat
 from .unet2d import Unet2D, Unet2DDRIVE
 from .unet3d import Unet
 from .attunet3d import AttUnet
+from .vnet3d import VNet
 
 
 class TMSU(nn.Module):
@@ -35,11 +36,17 @@ class TMSU(nn.Module):
                 backbone = Unet(in_channels=4, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
             elif model_name == 'AU' and input_modality == 'four':            # TrustworthySeg.py:40-41
                 backbone = AttUnet(in_channels=4, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
+            elif model_name == 'V' and input_modality == 'four':             # TrustworthySeg.py:42-44
+                backbone = VNet(n_channels=4, n_classes=num_classes, n_filters=16, normalization='gn',
+                                has_dropout=False, compute_dtype=dtype)
         elif dataset == 'LiTS':
             if model_name == 'U':
                 backbone = Unet(in_channels=1, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
             elif model_name == 'AU':                                         # TrustworthySeg.py:65
                 backbone = AttUnet(in_channels=1, base_channels=16, num_classes=num_classes, compute_dtype=dtype)
+            elif model_name == 'V':                                          # TrustworthySeg.py:67-69
+                backbone = VNet(n_channels=1, n_classes=num_classes, n_filters=16, normalization='gn',
+                                has_dropout=False, compute_dtype=dtype)
         elif dataset == 'ISIC':
             if model_name == 'U':
                 backbone = Unet2D(3, num_classes, compute_dtype=dtype)

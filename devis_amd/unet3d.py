@@ -403,6 +403,9 @@ class Unet(nn.Module):
         self._finish_init(compute_dtype, num_classes)
 
     _run_cls = None       # set below: the schedule class that executes this backbone
+    # gradient buckets for the overlapped all-reduce: (first parameter prefix of bucket 1 in reverse registration
+    # order, prefix every member of bucket 1 shares)
+    _bucket_marks = ("EnBlock4_4.", "EnBlock4_")
 
     def _finish_init(self, compute_dtype, num_classes):
         """Bookkeeping shared by the 3-D backbones: parameter order, conv modules to pack, flat gradient layout."""
@@ -417,10 +420,10 @@ class Unet(nn.Module):
         off, layout, bounds = 0, {}, []
         plist = list(self.named_parameters())
         for n, p_ in reversed(plist):
-            if n.startswith("EnBlock4_4.") and len(bounds) == 0:
+            if n.startswith(self._bucket_marks[0]) and len(bounds) == 0:
                 bounds.append(off)                   # end of bucket 0: endconv ... first decoder module
-            if len(bounds) == 1 and off > bounds[0] and not n.startswith("EnBlock4_"):
-                bounds.append(off)                   # end of bucket 1: EnBlock4_*
+            if len(bounds) == 1 and off > bounds[0] and not n.startswith(self._bucket_marks[1]):
+                bounds.append(off)                   # end of bucket 1: the deepest stage
             layout[n] = (off, p_.numel(), tuple(p_.shape))
             off += p_.numel()
         self._grad_layout, self._grad_total = layout, off
@@ -448,11 +451,12 @@ class Unet(nn.Module):
         return self._packer.pack()
 
     def forward_channels_last(self, x: Tensor) -> Tensor:
-        if x.dim() != 5 or x.shape[1] != self.InitConv.conv.in_channels:
-            raise ValueError("Unet expects (N, %d, D, H, W), got %s" % (self.InitConv.conv.in_channels, tuple(x.shape)))
+        first = self._conv_modules[0][1]                     # the network's first conv
+        if x.dim() != 5 or x.shape[1] != first.in_channels:
+            raise ValueError("%s expects (N, %d, D, H, W), got %s" % (type(self).__name__, first.in_channels, tuple(x.shape)))
         if any(s % 8 for s in x.shape[2:]):
             raise ValueError("Unet needs D, H, W divisible by 8 (three stride-2 stages), got %s" % (tuple(x.shape[2:]),))
-        ops.require_device(x, self.InitConv.conv.weight)
+        ops.require_device(x, first.weight)
         return _Unet3dFn.apply(self, x, *[p for _, p in self.named_parameters()])
 
     def forward(self, x: Tensor) -> Tensor:

@@ -151,6 +151,46 @@ def attunet3d_forward(sd: StateDict, x: Tensor, training: bool = True) -> Tensor
 
 
 # ----------------------------------------------------------------------------
+# 3D V-Net  (models/lib/VNet3D.py:5-31,66-117,145-235; normalization='gn', has_dropout=False as
+# TrustworthySeg.py:42-44,67-69 builds it)   SURVEY.md §8(f)-4
+# ----------------------------------------------------------------------------
+
+def _gn16_relu(sd: StateDict, key: str, x: Tensor) -> Tensor:
+    # nn.GroupNorm(num_groups=16, C) then ReLU: VNet3D.py:18-24
+    return F.relu(F.group_norm(x, 16, sd[key + ".weight"], sd[key + ".bias"], 1e-5))
+
+
+def _v_conv_block(sd: StateDict, name: str, x: Tensor, n_stages: int) -> Tensor:
+    # ConvBlock, VNet3D.py:5-31: (Conv3d k3 p1 -> GroupNorm(16) -> ReLU) x n_stages; Sequential indices 3i, 3i+1
+    for i in range(n_stages):
+        x = _gn16_relu(sd, "%s.conv.%d" % (name, 3 * i + 1), _conv(sd, "%s.conv.%d" % (name, 3 * i), x))
+    return x
+
+
+def _v_down(sd: StateDict, name: str, x: Tensor) -> Tensor:
+    # DownsamplingConvBlock, VNet3D.py:66-89: Conv3d k2 s2 p0 -> GroupNorm(16) -> ReLU
+    return _gn16_relu(sd, name + ".conv.1", _conv(sd, name + ".conv.0", x, stride=2, pad=0))
+
+
+def _v_up(sd: StateDict, name: str, x: Tensor) -> Tensor:
+    # UpsamplingDeconvBlock, VNet3D.py:92-117: ConvTranspose3d k2 s2 -> GroupNorm(16) -> ReLU
+    h = F.conv_transpose3d(x, sd[name + ".conv.0.weight"], sd[name + ".conv.0.bias"], stride=2)
+    return _gn16_relu(sd, name + ".conv.1", h)
+
+
+def vnet3d_forward(sd: StateDict, x: Tensor) -> Tensor:
+    """VNet.forward with has_dropout=False, VNet3D.py:180-235 (GroupNorm only: no train / eval difference)."""
+    x1 = _v_conv_block(sd, "block_one", x, 1)
+    x2 = _v_conv_block(sd, "block_two", _v_down(sd, "block_one_dw", x1), 2)
+    x3 = _v_conv_block(sd, "block_three", _v_down(sd, "block_two_dw", x2), 3)
+    x4 = _v_conv_block(sd, "block_four", _v_down(sd, "block_three_dw", x3), 3)
+    x5 = _v_conv_block(sd, "block_five", _v_up(sd, "block_four_up", x4) + x3, 3)
+    x6 = _v_conv_block(sd, "block_six", _v_up(sd, "block_five_up", x5) + x2, 3)
+    x7 = _v_conv_block(sd, "block_seven", _v_up(sd, "block_six_up", x6) + x1, 1)
+    return _conv(sd, "out_conv", x7, pad=0)
+
+
+# ----------------------------------------------------------------------------
 # 2D U-Net  (models/lib/UNet2DZoo.py:107-259)
 # ----------------------------------------------------------------------------
 
