@@ -19,6 +19,11 @@ int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void
 int conv1_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const void*, void*, hipStream_t);
 int conv1_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, const StatsArgs*, int64_t*,
                      hipStream_t);
+// the V-Net's k2-s2 down conv on the gather-GEMM kernels
+int conv2s2_fwd_mfma(const devis_conv_desc*, const void*, const void*, const float*, const void*, void*, hipStream_t);
+int conv2s2_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
+size_t conv2s2_wgrad_mfma_workspace(const devis_conv_desc*);
+int conv2s2_wgrad_mfma(const devis_conv_desc*, const void*, const void*, float*, float*, void*, size_t, hipStream_t);
 // head1x1.hip: the 16 -> 4 endconv
 int head_fwd(const devis_conv_desc*, const void*, const void*, const float*, const void*, void*, hipStream_t);
 int head_dgrad(const devis_conv_desc*, const void*, const void*, const void*, void*, const StatsArgs*, int64_t*, hipStream_t);
@@ -100,6 +105,8 @@ int devis_conv_fwd_stats(const devis_conv_desc* d, const void* x1, const void* x
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
     rc = conv1_fwd_mfma(d, x1, x2, w, bias, residual, y, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+    rc = conv2s2_fwd_mfma(d, x1, w, bias, residual, y, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
   return conv_fwd_direct(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
 }
@@ -126,6 +133,8 @@ int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void*
   if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;     // statistics only come from the MFMA kernels
   rc = conv3s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = conv2s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   return conv_dgrad_direct(d, dy, w, residual, dx1, dx2, s);
 }
 
@@ -136,8 +145,8 @@ int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, co
 
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d) {
   if (!conv_desc_ok(d)) return 0;
-  const size_t a = conv_wgrad_mfma_workspace(d), b = conv1_wgrad_mfma_workspace(d);
-  return a > b ? a : b;
+  const size_t a = conv_wgrad_mfma_workspace(d), b = conv1_wgrad_mfma_workspace(d), c = conv2s2_wgrad_mfma_workspace(d);
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, const float* in_scale,
@@ -151,6 +160,8 @@ int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, c
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   if (!in_scale) {
     rc = conv1_wgrad_mfma(d, x1, x2, dy, dw, dbias, ws, ws_bytes, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+    rc = conv2s2_wgrad_mfma(d, x1, dy, dw, dbias, ws, ws_bytes, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
   return conv_wgrad_direct(d, x1, x2, in_scale, in_shift, dy, dw, dbias, s);

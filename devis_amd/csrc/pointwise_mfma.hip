@@ -1,7 +1,8 @@
 // MFMA "gather-GEMM" for the layers without a spatial halo (bf16 channels-last, gfx950):
 //   1x1 conv forward (virtual concat of two inputs) and its dgrad (two outputs),
 //   ConvTranspose k2s2 forward (scatter store) and dgrad (gather over the 2x2x2 taps),
-//   dgrad of the stride-2 3x3x3 convs (one GEMM per output-parity class, 1/2/4/8 taps).
+//   dgrad of the stride-2 3x3x3 convs (one GEMM per output-parity class, 1/2/4/8 taps),
+//   the k2-s2 'down' conv of the V-Net: forward = the ConvT-dgrad gather, dgrad = the ConvT-forward scatter.
 // out[m][v] = sum_k A[m][k] * B[k][v]: M = output channels (x taps for ConvT fwd), N = 16 voxels along W,
 // K = source channels (x taps).  B fragments are 16-byte global loads (every source byte is used once, so
 // there is nothing to stage in LDS); A fragments (weights) come from L1/L2.  These layers are HBM-bound.
@@ -10,7 +11,7 @@
 
 namespace devis {
 
-enum { PW_CONV1 = 0, PW_CONVT_FWD = 1, PW_CONVT_DGRAD = 2, PW_S2_DGRAD = 3 };
+enum { PW_CONV1 = 0, PW_CONVT_FWD = 1, PW_CONVT_DGRAD = 2, PW_S2_DGRAD = 3, PW_DOWN_DGRAD = 4 };
 
 struct PwArgs {
   const bf16* x1; const bf16* x2; const bf16* w; const float* bias; const bf16* res;
@@ -39,7 +40,7 @@ template <int MODE>
 __device__ __forceinline__ uint4 pw_load_b(const PwArgs& a, int k0, int n, int d, int h, int w, bool vox_ok, int cls) {
   uint4 z = make_uint4(0u, 0u, 0u, 0u);
   if (!vox_ok || k0 >= a.K) return z;
-  if (MODE == PW_CONV1 || MODE == PW_CONVT_FWD) {
+  if (MODE == PW_CONV1 || MODE == PW_CONVT_FWD || MODE == PW_DOWN_DGRAD) {
     const size_t v = ((size_t)(n * a.D + d) * a.H + h) * a.W + w;
     if (k0 < a.C1) return pw_piece(a.x1 + v * a.C1, k0, a.C1);
     return pw_piece(a.x2 + v * a.C2, k0 - a.C1, a.C2);
@@ -67,6 +68,10 @@ template <int MODE>
 __device__ __forceinline__ uint4 pw_load_a(const PwArgs& a, int m, int k0, int cls) {
   uint4 z = make_uint4(0u, 0u, 0u, 0u);
   if (m >= a.M || k0 >= a.K) return z;
+  if (MODE == PW_DOWN_DGRAD) {   // row m = (tap p, ci c) of the conv-dgrad packing [Cin][T reversed][Cout]
+    const int T = a.KD * a.KH * a.KW, p = m / a.Cs, c = m % a.Cs;
+    return pw_piece(a.w + ((size_t)c * T + (T - 1 - p)) * a.K, k0, a.K);
+  }
   if (MODE != PW_S2_DGRAD) return pw_piece(a.w + (size_t)m * a.K, k0, a.K);
   const int tj = k0 / a.Cs, c = k0 % a.Cs;
   const int bw = cls & 1, bh = (cls >> 1) & 1, bd = (cls >> 2) & 1;
@@ -177,12 +182,16 @@ k_pw_mfma(PwArgs a) {
             const uint2 r = *reinterpret_cast<const uint2*>(a.res + v * a.M1 + mrow);
             v0 += bf_lo(r.x); v1 += bf_hi(r.x); v2 += bf_lo(r.y); v3 += bf_hi(r.y);
           }
-        } else if (MODE == PW_CONVT_FWD) {
+        } else if (MODE == PW_CONVT_FWD || MODE == PW_DOWN_DGRAD) {
           const int p = mrow / a.Cs, c = mrow % a.Cs;
           const int pw = p % a.KW, ph = (p / a.KW) % a.KH, pd = p / (a.KW * a.KH);
           const size_t ov = ((size_t)(nn[j] * a.OD + dd[j] * a.KD + pd) * a.OH + hh[j] * a.KH + ph) * a.OW + ww[j] * a.KW + pw;
           dst = a.y1 + ov * a.Cs + c;
           brow = c;
+          if (MODE == PW_DOWN_DGRAD && a.res) {
+            const uint2 r = *reinterpret_cast<const uint2*>(a.res + ov * a.Cs + c);
+            v0 += bf_lo(r.x); v1 += bf_hi(r.x); v2 += bf_lo(r.y); v3 += bf_hi(r.y);
+          }
         } else if (MODE == PW_CONVT_DGRAD) {
           const size_t v = ((size_t)(nn[j] * a.D + dd[j]) * a.H + hh[j]) * a.W + ww[j];
           dst = a.y1 + v * a.M + mrow;
@@ -324,6 +333,40 @@ int conv3s2_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_d
   const int64_t blocks = cdiv(ntiles, a.M >= 64 ? 8 : 16);
   (void)blocks;                      // measured on EnDown1 (128^3): looping the classes in the block is no faster (164 vs 154 us)
   return pw_launch<PW_S2_DGRAD>(a, 8, s);
+}
+
+// ---- k2-s2-p0 'down' conv (V-Net): forward gathers the 8 fine taps (the ConvT-dgrad GEMM on the packed conv
+// weight [Cout][8][Cin], plus bias); dgrad scatters to the 8 fine positions (the ConvT-forward GEMM on the
+// conv-dgrad packing), plus an optional residual (the skip gradient)
+static bool down_shape(const devis_conv_desc* d) {
+  return d->dtype == DEVIS_BF16 && d->KD == 2 && d->KH == 2 && d->KW == 2 && d->SD == 2 && d->SH == 2 && d->SW == 2 &&
+         d->PD == 0 && d->PH == 0 && d->PW == 0 && d->C2 == 0 && d->ID == 2 * d->OD && d->IH == 2 * d->OH &&
+         d->IW == 2 * d->OW && d->C1 % 8 == 0 && d->Cout % 8 == 0 && small_enough(d->N * d->ID * d->IH * d->IW);
+}
+
+int conv2s2_fwd_mfma(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y,
+                     hipStream_t s) {
+  if (!down_shape(d) || res) return DEVIS_ERR_UNSUPPORTED;
+  PwArgs a = {};
+  a.x1 = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y1 = (bf16*)y;
+  a.Cs = (int)d->C1; a.KD = a.KH = a.KW = 2;
+  a.K = a.Cs * 8; a.M = (int)d->Cout; a.M1 = a.M;
+  a.N = (int)d->N; a.D = (int)d->OD; a.H = (int)d->OH; a.W = (int)d->OW;
+  a.OD = (int)d->ID; a.OH = (int)d->IH; a.OW = (int)d->IW;
+  return pw_launch<PW_CONVT_DGRAD>(a, 1, s);
+}
+
+int conv2s2_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_dgrad, const void* res, void* dx,
+                       hipStream_t s) {
+  if (!w_dgrad || !down_shape(d)) return DEVIS_ERR_UNSUPPORTED;
+  PwArgs a = {};
+  a.x1 = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.res = (const bf16*)res; a.y1 = (bf16*)dx;
+  a.C1 = (int)d->Cout; a.C2 = 0; a.K = a.C1; a.Cs = (int)d->C1;
+  a.KD = a.KH = a.KW = 2;
+  a.M = a.Cs * 8; a.M1 = a.M;
+  a.N = (int)d->N; a.D = (int)d->OD; a.H = (int)d->OH; a.W = (int)d->OW;
+  a.OD = (int)d->ID; a.OH = (int)d->IH; a.OW = (int)d->IW;
+  return pw_launch<PW_DOWN_DGRAD>(a, 1, s);
 }
 
 // ---- ConvTranspose (kernel == stride) forward and dgrad

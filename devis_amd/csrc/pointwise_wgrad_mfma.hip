@@ -110,7 +110,7 @@ k_pw_wgrad(PwWgArgs a) {
       const int i = lane + 64 * k;
       const int v = i / MPPV, pc = i % MPPV;
       const uint4 val = mr[k];
-      if (a.bias_side == 1) {
+      if (a.bias_side == 1 && blockIdx.y == 0) {      // M-side bias: once, not once per tap slice
         bsum[0] += bf_lo(val.x); bsum[1] += bf_hi(val.x); bsum[2] += bf_lo(val.y); bsum[3] += bf_hi(val.y);
         bsum[4] += bf_lo(val.z); bsum[5] += bf_hi(val.z); bsum[6] += bf_lo(val.w); bsum[7] += bf_hi(val.w);
       }
@@ -191,16 +191,30 @@ k_pw_wgrad(PwWgArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) wred[lane * 8 + j] = bsum[j];
     __syncthreads();
-    float s = 0.f;
-    if (lane < PPV * 8) {
-      const int pc = lane / 8, j = lane % 8;
-      for (int k = pc; k < 64; k += PPV) s += wred[k * 8 + j];
+    // channel cb = 8 * piece + j; up to 128 bias channels: two rounds of 64 lanes
+    // (`red` aliases wave 0's `wred`, so both rounds are read out before `red` is written)
+    float s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int cb = r * 64 + lane;
+      if (cb < PPV * 8) {
+        const int pc = cb / 8, j = cb % 8;
+        for (int k = pc; k < 64; k += PPV) s2[r] += wred[k * 8 + j];
+      }
     }
     __syncthreads();
-    red[wave * 64 + lane] = s;
+    red[wave * 64 + lane] = s2[0];
+    red[256 + wave * 64 + lane] = s2[1];
     __syncthreads();
-    if (wave == 0 && lane < PPV * 8 && lane < Cb)
-      a.bpart[(pidx * T + tap) * Cb + lane] = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int cb = r * 64 + lane;
+        const float* rr = red + r * 256;
+        if (cb < PPV * 8 && cb < Cb)
+          a.bpart[(pidx * T + tap) * Cb + cb] = ((rr[lane] + rr[64 + lane]) + rr[128 + lane]) + rr[192 + lane];
+      }
+    }
   }
 }
 
@@ -240,6 +254,9 @@ static int pw_wgrad_launch(PwWgArgs& a, const PwWgPlan& pl, int Cb, float* dw, f
   else if (mto == 1 && mti == 1) PWG(1, 1);
   else if (mto == 4 && mti == 4) PWG(4, 4);
   else if (mto == 2 && mti == 2) PWG(2, 2);
+  else if (mto == 2 && mti == 1) PWG(2, 1);          // the k2-s2 down convs (Cout = 2 Cin)
+  else if (mto == 4 && mti == 2) PWG(4, 2);
+  else if (mto == 8 && mti == 4) PWG(8, 4);
   else return DEVIS_ERR_UNSUPPORTED;
 #undef PWG
   int rc = launch_status();
@@ -256,7 +273,8 @@ static int pw_wgrad_launch(PwWgArgs& a, const PwWgPlan& pl, int Cb, float* dw, f
 static bool pw_tiles_ok(int M, int N) {
   const int mto = (M + 15) / 16, mti = (N + 15) / 16;
   return (mto == 4 && mti == 8) || (mto == 2 && mti == 4) || (mto == 1 && mti == 2) || (mto == 1 && mti == 1) ||
-         (mto == 4 && mti == 4) || (mto == 2 && mti == 2);
+         (mto == 4 && mti == 4) || (mto == 2 && mti == 2) || (mto == 2 && mti == 1) || (mto == 4 && mti == 2) ||
+         (mto == 8 && mti == 4);
 }
 
 static bool conv1_wgrad_ok(const devis_conv_desc* d) {
@@ -310,6 +328,35 @@ int convT_wgrad_mfma(const devis_convT_desc* d, const void* x, const void* dy, f
   const PwWgPlan pl = pw_plan(a.NV, T, a.M, a.N, a.N);
   if (!ws || ws_bytes < pl.total_bytes) return DEVIS_ERR_WORKSPACE;
   return pw_wgrad_launch<PWG_CONVT>(a, pl, a.N, dw, dbias, ws, s);
+}
+
+// ---- k2-s2-p0 'down' conv wgrad: dw[co][ci][t] = sum dy_coarse[co] * x_fine[tap t][ci] - the ConvT wgrad GEMM with
+// the coarse tensor on the M side - and dbias[co] = sum dy_coarse[co] (M-side bias)
+static bool down_wgrad_ok(const devis_conv_desc* d) {
+  return d->dtype == DEVIS_BF16 && d->KD == 2 && d->KH == 2 && d->KW == 2 && d->SD == 2 && d->SH == 2 && d->SW == 2 &&
+         d->PD == 0 && d->PH == 0 && d->PW == 0 && d->C2 == 0 && d->ID == 2 * d->OD && d->IH == 2 * d->OH &&
+         d->IW == 2 * d->OW && d->C1 % 8 == 0 && d->Cout % 8 == 0 && pw_tiles_ok((int)d->Cout, (int)d->C1);
+}
+
+size_t conv2s2_wgrad_mfma_workspace(const devis_conv_desc* d) {
+  if (!down_wgrad_ok(d)) return 0;
+  return pw_plan(d->N * d->OD * d->OH * d->OW, 8, (int)d->Cout, (int)d->C1, (int)d->Cout).total_bytes;
+}
+
+int conv2s2_wgrad_mfma(const devis_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* ws,
+                       size_t ws_bytes, hipStream_t s) {
+  if (!down_wgrad_ok(d)) return DEVIS_ERR_UNSUPPORTED;
+  PwWgArgs a = {};
+  a.msrc = (const bf16*)dy; a.n1 = (const bf16*)x;
+  a.M = (int)d->Cout; a.N = (int)d->C1;
+  a.NB = (int)d->N; a.D = (int)d->OD; a.H = (int)d->OH; a.W = (int)d->OW;
+  a.KD = a.KH = a.KW = 2;
+  a.OD = (int)d->ID; a.OH = (int)d->IH; a.OW = (int)d->IW;
+  a.NV = d->N * d->OD * d->OH * d->OW;
+  a.bias_side = dbias ? 1 : 0;
+  const PwWgPlan pl = pw_plan(a.NV, 8, a.M, a.N, a.M);
+  if (!ws || ws_bytes < pl.total_bytes) return DEVIS_ERR_WORKSPACE;
+  return pw_wgrad_launch<PWG_CONVT>(a, pl, a.M, dw, dbias, ws, s);
 }
 
 }  // namespace devis

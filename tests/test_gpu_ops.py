@@ -49,6 +49,10 @@ CONV_CASES = [
     (1, 32, 32, 32, (4, 4, 16), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (2, 16, 0, 4, (8, 8, 16), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (1, 4, 0, 16, (8, 8, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    # k2-s2-p0 'down' convs of the V-Net (gather-GEMM kernels in bf16), one with a ragged coarse row
+    (2, 16, 0, 32, (8, 8, 32), (2, 2, 2), (2, 2, 2), (0, 0, 0)),
+    (1, 32, 0, 64, (4, 8, 40), (2, 2, 2), (2, 2, 2), (0, 0, 0)),
+    (1, 64, 0, 128, (4, 4, 32), (2, 2, 2), (2, 2, 2), (0, 0, 0)),
 ]
 
 
@@ -100,6 +104,12 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, prologue):
     dw, db = ops.conv_wgrad(x1, x2, cl(dy, dtype), geom, w.shape, scg, shg)
     assert rel_err(dw, wr.grad) < tol(dtype)
     assert rel_err(db, br.grad) < tol(dtype)
+    if k == (2, 2, 2):            # the skip gradient the V-Net adds in this dgrad's epilogue
+        rs = torch.randn(x[:, :c1].shape, generator=g)
+        if dtype == torch.bfloat16:
+            rs = rs.bfloat16().float()
+        dxr, _ = ops.conv_dgrad(cl(dy, dtype), wp, geom, x1.shape, c2, residual=cl(rs, dtype))
+        assert rel_err(uncl(dxr), da[:, :c1] + rs) < tol(dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
