@@ -15,6 +15,14 @@ int conv_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*,
                   const float*, const void*, void*, const StatsArgs*, int64_t*, hipStream_t);
 int conv_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, const StatsArgs*,
                     int64_t*, hipStream_t);
+// conv2d_mfma.hip: the 2-D U-Nets' 3x3 layers
+int conv2d_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
+                    const float*, const void*, void*, const StatsArgs*, int64_t*, hipStream_t);
+int conv2d_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, const StatsArgs*,
+                      int64_t*, hipStream_t);
+size_t conv2d_wgrad_mfma_workspace(const devis_conv_desc*);
+int conv2d_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
+                      float*, float*, void*, size_t, hipStream_t);
 // pointwise_mfma.hip
 int conv1_fwd_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const void*, void*, hipStream_t);
 int conv1_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, const StatsArgs*, int64_t*,
@@ -78,12 +86,18 @@ int64_t devis_conv_stats_chunks(const devis_conv_desc* d, int dgrad, int mode, i
     if (has_prologue) return 0;
     rc = conv_dgrad_mfma(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph), nullptr, &st, &chunks, nullptr);
     if (rc == DEVIS_ERR_UNSUPPORTED)
+      rc = conv2d_dgrad_mfma(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph),
+                             d->C2 ? const_cast<void*>(ph) : nullptr, &st, &chunks, nullptr);
+    if (rc == DEVIS_ERR_UNSUPPORTED)
       rc = head_dgrad(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph), &st, &chunks, nullptr);
     if (rc == DEVIS_ERR_UNSUPPORTED && d->C2 == 0)      // 1x1 layers: the gather-GEMM kernel
       rc = conv1_dgrad_mfma(d, ph, ph, has_residual ? ph : nullptr, const_cast<void*>(ph), nullptr, &st, &chunks, nullptr);
   } else {
     rc = conv_fwd_mfma(d, ph, nullptr, ph, phf, has_prologue ? phf : nullptr, has_prologue ? phf : nullptr,
                        has_residual ? ph : nullptr, const_cast<void*>(ph), &st, &chunks, nullptr);
+    if (rc == DEVIS_ERR_UNSUPPORTED)
+      rc = conv2d_fwd_mfma(d, ph, d->C2 ? ph : nullptr, ph, phf, has_prologue ? phf : nullptr, has_prologue ? phf : nullptr,
+                           has_residual ? ph : nullptr, const_cast<void*>(ph), &st, &chunks, nullptr);
   }
   return rc == DEVIS_OK ? chunks : 0;
 }
@@ -99,6 +113,7 @@ int devis_conv_fwd_stats(const devis_conv_desc* d, const void* x1, const void* x
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   rc = conv_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, &st, nullptr, s);
+  if (rc == DEVIS_ERR_UNSUPPORTED) rc = conv2d_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;      // statistics only come from the MFMA kernels
   if (!in_scale) {
     rc = head_fwd(d, x1, w, bias, residual, y, s);
@@ -127,6 +142,8 @@ int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void*
   hipStream_t s = (hipStream_t)stream;
   rc = conv_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = conv2d_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = head_dgrad(d, dy, w, residual, dx1, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = conv1_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
@@ -145,8 +162,11 @@ int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, co
 
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d) {
   if (!conv_desc_ok(d)) return 0;
-  const size_t a = conv_wgrad_mfma_workspace(d), b = conv1_wgrad_mfma_workspace(d), c = conv2s2_wgrad_mfma_workspace(d);
-  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+  const size_t v[4] = {conv_wgrad_mfma_workspace(d), conv1_wgrad_mfma_workspace(d), conv2s2_wgrad_mfma_workspace(d),
+                       conv2d_wgrad_mfma_workspace(d)};
+  size_t m = 0;
+  for (size_t b : v) m = b > m ? b : m;
+  return m;
 }
 
 int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, const float* in_scale,
@@ -157,6 +177,8 @@ int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, c
   if ((in_scale != nullptr) != (in_shift != nullptr)) return DEVIS_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   int rc = conv_wgrad_mfma(d, x1, x2, in_scale, in_shift, dy, dw, dbias, ws, ws_bytes, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = conv2d_wgrad_mfma(d, x1, x2, in_scale, in_shift, dy, dw, dbias, ws, ws_bytes, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   if (!in_scale) {
     rc = conv1_wgrad_mfma(d, x1, x2, dy, dw, dbias, ws, ws_bytes, s);

@@ -18,7 +18,7 @@ struct RedArgs {
   int nparts, nbparts, Cb;
   int64_t pstride;      // floats between partials
   int64_t total;        // floats of a partial that are summed (multiple of 4)
-  int mode;             // RED_CONV3: o = (t*A + co)*B + ci -> dw[(co*cin_real + ci)*27 + t], ci < cin_real
+  int mode;             // RED_CONV3: o = (t*A + co)*B + ci -> dw[(co*cin_real + ci)*T + t], ci < cin_real, T = total/(A*B)
   int A, B, cin_real;   // RED_PW:    o = p*B + mn          -> dw[mn*A + p]   (A = taps T, B = M*N)
 };
 
@@ -80,7 +80,8 @@ k_reduce_partials(RedArgs a) {
       const int64_t o = o4 * 4 + j;
       if (MODE == RED_CONV3) {
         const int ci = (int)(o % a.B), co = (int)((o / a.B) % a.A), t = (int)(o / ((int64_t)a.A * a.B));
-        if (ci < a.cin_real) a.dw[((int64_t)co * a.cin_real + ci) * 27 + t] = sv[j];
+        const int T = (int)(a.total / ((int64_t)a.A * a.B));          // 27 (3x3x3) or 9 (3x3)
+        if (ci < a.cin_real) a.dw[((int64_t)co * a.cin_real + ci) * T + t] = sv[j];
       } else {
         const int64_t mn = o % a.B;
         const int p = (int)(o / a.B);

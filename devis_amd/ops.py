@@ -291,7 +291,8 @@ def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, r
     lib = _lib.load()
     if wd is None and dy.dtype == torch.bfloat16 and ((c2 == 0 and geom.k == (3, 3, 3) and geom.s in ((1, 1, 1), (2, 2, 2)))
                                                       or geom.k == (1, 1, 1)
-                                                      or (c2 == 0 and geom.k == (2, 2, 2) and geom.s == (2, 2, 2))):
+                                                      or (c2 == 0 and geom.k == (2, 2, 2) and geom.s == (2, 2, 2))
+                                                      or (geom.k == (1, 3, 3) and geom.s == (1, 1, 1))):
         # tap-flipped [Cin][T][Cout] packing: dgrad runs on the MFMA forward kernel
         wd = torch.empty((wp.shape[2], wp.shape[1], wp.shape[0]), dtype=wp.dtype, device=wp.device)
         check(lib.devis_repack_conv_weight_dgrad(_p(wp), _p(wd), wp.shape[0], wp.shape[2], wp.shape[1],

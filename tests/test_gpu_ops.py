@@ -53,6 +53,15 @@ CONV_CASES = [
     (2, 16, 0, 32, (8, 8, 32), (2, 2, 2), (2, 2, 2), (0, 0, 0)),
     (1, 32, 0, 64, (4, 8, 40), (2, 2, 2), (2, 2, 2), (0, 0, 0)),
     (1, 64, 0, 128, (4, 4, 32), (2, 2, 2), (2, 2, 2), (0, 0, 0)),
+    # 3x3 layers of the 2-D U-Nets on the MFMA kernels (bf16): every (cout tile, tile height) variant,
+    # ragged tiles, two-input (virtual concat) layers, many K chunks
+    (2, 32, 0, 32, (16, 16), (3, 3), (1, 1), (1, 1)),
+    (1, 32, 32, 32, (20, 40), (3, 3), (1, 1), (1, 1)),
+    (2, 64, 64, 64, (9, 18), (3, 3), (1, 1), (1, 1)),
+    (1, 256, 0, 128, (8, 16), (3, 3), (1, 1), (1, 1)),
+    (3, 128, 0, 256, (16, 16), (3, 3), (1, 1), (1, 1)),
+    (8, 32, 0, 64, (128, 128), (3, 3), (1, 1), (1, 1)),
+    (8, 32, 0, 32, (128, 128), (3, 3), (1, 1), (1, 1)),
 ]
 
 
