@@ -32,7 +32,11 @@ int conv2s2_fwd_mfma(const devis_conv_desc*, const void*, const void*, const flo
 int conv2s2_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
 size_t conv2s2_wgrad_mfma_workspace(const devis_conv_desc*);
 int conv2s2_wgrad_mfma(const devis_conv_desc*, const void*, const void*, float*, float*, void*, size_t, hipStream_t);
-// head1x1.hip: the 16 -> 4 endconv
+// conv_thin.hip: the 2-D nets' first layer (1 or 3 input channels)
+int first2d_fwd(const devis_conv_desc*, const void*, const void*, const float*, const void*, void*, hipStream_t);
+size_t first2d_wgrad_workspace(const devis_conv_desc*);
+int first2d_wgrad(const devis_conv_desc*, const void*, const void*, float*, float*, void*, size_t, hipStream_t);
+// head1x1.hip: the 16 -> 4 endconv (and the 2-D nets' 32 -> 2 conv10)
 int head_fwd(const devis_conv_desc*, const void*, const void*, const float*, const void*, void*, hipStream_t);
 int head_dgrad(const devis_conv_desc*, const void*, const void*, const void*, void*, const StatsArgs*, int64_t*, hipStream_t);
 int conv3s2_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
@@ -122,6 +126,8 @@ int devis_conv_fwd_stats(const devis_conv_desc* d, const void* x1, const void* x
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
     rc = conv2s2_fwd_mfma(d, x1, w, bias, residual, y, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+    rc = first2d_fwd(d, x1, w, bias, residual, y, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
   return conv_fwd_direct(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
 }
@@ -162,8 +168,8 @@ int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, co
 
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d) {
   if (!conv_desc_ok(d)) return 0;
-  const size_t v[4] = {conv_wgrad_mfma_workspace(d), conv1_wgrad_mfma_workspace(d), conv2s2_wgrad_mfma_workspace(d),
-                       conv2d_wgrad_mfma_workspace(d)};
+  const size_t v[5] = {conv_wgrad_mfma_workspace(d), conv1_wgrad_mfma_workspace(d), conv2s2_wgrad_mfma_workspace(d),
+                       conv2d_wgrad_mfma_workspace(d), first2d_wgrad_workspace(d)};
   size_t m = 0;
   for (size_t b : v) m = b > m ? b : m;
   return m;
@@ -184,6 +190,8 @@ int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, c
     rc = conv1_wgrad_mfma(d, x1, x2, dy, dw, dbias, ws, ws_bytes, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
     rc = conv2s2_wgrad_mfma(d, x1, dy, dw, dbias, ws, ws_bytes, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+    rc = first2d_wgrad(d, x1, dy, dw, dbias, ws, ws_bytes, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
   return conv_wgrad_direct(d, x1, x2, in_scale, in_shift, dy, dw, dbias, s);

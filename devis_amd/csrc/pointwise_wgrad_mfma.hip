@@ -25,6 +25,8 @@ struct PwWgArgs {
   float* part;                   // [nparts][T][M][N]
   float* bpart;                  // [nparts][T][Cb] or null
   int bias_side;                 // 1: bias channels are the M side (CONV1), 2: the N side (CONVT)
+  // wide ConvT layers: grid.z slabs of M x N channels out of rows ldm / ldn wide (slab z = ns * nms + ms)
+  int ldm, ldn, nms;
 };
 
 __device__ __forceinline__ bf16x8 tr_pair2(const char* p0, const char* p1) {
@@ -35,11 +37,12 @@ __device__ __forceinline__ bf16x8 tr_pair2(const char* p0, const char* p1) {
   return u.v;
 }
 
-// load up to 8 channels [c, c+8) of a row with C channels (C % 4 == 0), zero-extended
+// load up to 8 channels [c, c+8) of a row with C channels (C % 4 == 0, or C == 2), zero-extended
 __device__ __forceinline__ uint4 load_piece(const bf16* row, int c, int C) {
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
   if (c + 8 <= C) v = *reinterpret_cast<const uint4*>(row + c);
   else if (c + 4 <= C) { const uint2 t = *reinterpret_cast<const uint2*>(row + c); v.x = t.x; v.y = t.y; }
+  else if (c + 2 <= C) v.x = *reinterpret_cast<const unsigned*>(row + c);      // the 2-class head of the 2-D nets
   return v;
 }
 
@@ -52,6 +55,9 @@ k_pw_wgrad(PwWgArgs a) {
   char* mimg = smem + wave * (MTO + MTI) * 1024;
   char* nimg = mimg + MTO * 1024;
   const int tap = blockIdx.y;
+  const int zs = blockIdx.z, ms = zs % a.nms, ns = zs / a.nms;
+  const bf16* msrc = a.msrc + ms * a.M;
+  const bf16* nsrc = a.n1 + ns * a.N;          // ConvT only (a 1x1 layer is one slab)
   const int tw = tap % a.KW, th = (tap / a.KW) % a.KH, td = tap / (a.KW * a.KH);
 
   f32x4 acc[MTO][MTI];
@@ -76,7 +82,7 @@ k_pw_wgrad(PwWgArgs a) {
       const int v = i / MPPV, pc = i % MPPV;
       const int64_t gv = v0 + v;
       mr[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (gv < a.NV) mr[k] = load_piece(a.msrc + gv * a.M, pc * 8, a.M);
+      if (gv < a.NV) mr[k] = load_piece(msrc + gv * a.ldm, pc * 8, a.M);
     }
 #pragma unroll
     for (int k = 0; k < MTI; ++k) {
@@ -96,7 +102,7 @@ k_pw_wgrad(PwWgArgs a) {
           const int d = (int)(r % a.D);
           const int n = (int)(r / a.D);
           const int64_t ov = ((int64_t)(n * a.OD + d * a.KD + td) * a.OH + h * a.KH + th) * a.OW + w * a.KW + tw;
-          val = load_piece(a.n1 + ov * a.N, c, a.N);
+          val = load_piece(nsrc + ov * a.ldn, c, a.N);
         }
       }
       nr[k] = val;
@@ -168,7 +174,7 @@ k_pw_wgrad(PwWgArgs a) {
   const int T = gridDim.y;
   const int64_t pidx = blockIdx.x;
   if (wave == 0) {
-    float* part = a.part + (pidx * T + tap) * a.M * a.N;
+    float* part = a.part + ((pidx * T + tap) * gridDim.z + zs) * a.M * a.N;
 #pragma unroll
     for (int mo = 0; mo < MTO; ++mo)
 #pragma unroll
@@ -185,7 +191,9 @@ k_pw_wgrad(PwWgArgs a) {
     // lanes with equal (lane % PPV) hold the same 8 channels: combine them through LDS (fixed order),
     // then the four waves in wave order
     const int PPV = a.bias_side == 1 ? MPPV : NPPV;
-    const int Cb = a.bias_side == 1 ? a.M : a.N;
+    const int Cb = a.bias_side == 1 ? a.M : a.N * (int)(gridDim.z / a.nms);     // all bias channels
+    const int cboff = a.bias_side == 1 ? 0 : ns * a.N;
+    const bool bwrite = a.bias_side == 1 || ms == 0;
     __syncthreads();
     float* wred = reinterpret_cast<float*>(mimg);     // [64][8] floats = 2 KB <= the wave's own region
 #pragma unroll
@@ -211,8 +219,8 @@ k_pw_wgrad(PwWgArgs a) {
       for (int r = 0; r < 2; ++r) {
         const int cb = r * 64 + lane;
         const float* rr = red + r * 256;
-        if (cb < PPV * 8 && cb < Cb)
-          a.bpart[(pidx * T + tap) * Cb + cb] = ((rr[lane] + rr[64 + lane]) + rr[128 + lane]) + rr[192 + lane];
+        if (bwrite && cb < PPV * 8 && cboff + cb < Cb)
+          a.bpart[(pidx * T + tap) * Cb + cboff + cb] = ((rr[lane] + rr[64 + lane]) + rr[128 + lane]) + rr[192 + lane];
       }
     }
   }
@@ -220,13 +228,13 @@ k_pw_wgrad(PwWgArgs a) {
 
 struct PwWgPlan { int gx, iters, nparts, T; size_t part_bytes, total_bytes; };
 
-static PwWgPlan pw_plan(int64_t NV, int T, int M, int N, int Cb) {
+static PwWgPlan pw_plan(int64_t NV, int T, int M, int N, int Cb, int nz = 1) {
   PwWgPlan p;
   const int64_t segs = cdiv(NV, 32);
   // every block leaves one fp32 partial [T-slice][M][N]: enough blocks to keep several waves per SIMD in
   // flight on the big layers (their partials are tiny), but at most ~16 MB of partials in total
   int64_t gx = cdiv(segs, 4);
-  int64_t cap = 1024 / T;
+  int64_t cap = 1024 / (T * nz);
   const int64_t by_bytes = ((int64_t)16 << 20) / ((int64_t)T * M * N * (int64_t)sizeof(float));
   if (by_bytes < cap) cap = by_bytes;
   if (cap < 16) cap = 16;
@@ -245,8 +253,11 @@ static int pw_wgrad_launch(PwWgArgs& a, const PwWgPlan& pl, int Cb, float* dw, f
   a.iters = pl.iters;
   a.part = (float*)ws;
   a.bpart = dbias ? (float*)((char*)ws + pl.part_bytes) : nullptr;
+  int nz = 1, ntot = a.N;
+  if (a.nms == 0) { a.nms = 1; a.ldm = a.M; a.ldn = a.N; }
+  else { nz = a.nms * (a.ldn / a.N); ntot = a.ldn; }
   const int mto = (int)cdiv(a.M, 16), mti = (int)cdiv(a.N, 16);
-  const dim3 grid((unsigned)pl.gx, (unsigned)pl.T);
+  const dim3 grid((unsigned)pl.gx, (unsigned)pl.T, (unsigned)nz);
 #define PWG(MO, MI) hipLaunchKernelGGL((k_pw_wgrad<MODE, MO, MI>), grid, dim3(256), 4 * (MO + MI) * 1024, s, a)
   if (mto == 4 && mti == 8) PWG(4, 8);
   else if (mto == 2 && mti == 4) PWG(2, 4);
@@ -265,8 +276,9 @@ static int pw_wgrad_launch(PwWgArgs& a, const PwWgPlan& pl, int Cb, float* dw, f
   RedArgs r;
   r.part = a.part; r.bpart = a.bpart; r.dw = dw; r.dbias = dbias;
   r.nparts = pl.nparts; r.nbparts = pl.nparts * pl.T; r.Cb = Cb;
-  r.pstride = (int64_t)pl.T * a.M * a.N; r.total = r.pstride;
-  r.mode = RED_PW; r.A = pl.T; r.B = a.M * a.N; r.cin_real = 0;
+  r.pstride = (int64_t)pl.T * nz * a.M * a.N; r.total = r.pstride;
+  r.mode = RED_PW; r.A = pl.T; r.B = nz * a.M * a.N; r.cin_real = 0;
+  if (nz > 1) { r.nms = a.nms; r.msub = a.M; r.nsub = a.N; r.ntot = ntot; }
   return launch_reduce_partials(r, s);
 }
 
@@ -280,7 +292,7 @@ static bool pw_tiles_ok(int M, int N) {
 static bool conv1_wgrad_ok(const devis_conv_desc* d) {
   if (d->dtype != DEVIS_BF16 || d->KD != 1 || d->KH != 1 || d->KW != 1 || d->SD != 1 || d->SH != 1 || d->SW != 1) return false;
   if (d->PD || d->PH || d->PW) return false;
-  if (d->Cout % 4 || d->C1 % 8 || d->C2 % 8) return false;
+  if ((d->Cout % 4 && d->Cout != 2) || d->C1 % 8 || d->C2 % 8) return false;
   return pw_tiles_ok((int)d->Cout, (int)(d->C1 + d->C2));
 }
 
@@ -303,14 +315,18 @@ int conv1_wgrad_mfma(const devis_conv_desc* d, const void* x1, const void* x2, c
   return pw_wgrad_launch<PWG_CONV1>(a, pl, a.M, dw, dbias, ws, s);
 }
 
+// wide layers (the 2-D U-Net's 256 -> 128 and 512 -> 256) run as grid.z slabs of 128 x 64 channels
+static bool convT_wide(const devis_convT_desc* d) { return d->Cin > 128 && d->Cin % 128 == 0 && d->Cout % 64 == 0; }
+
 static bool convT_wgrad_ok(const devis_convT_desc* d) {
   if (d->dtype != DEVIS_BF16 || d->Cin % 8 || d->Cout % 8) return false;
-  return pw_tiles_ok((int)d->Cin, (int)d->Cout);
+  return convT_wide(d) || pw_tiles_ok((int)d->Cin, (int)d->Cout);
 }
 
 size_t convT_wgrad_mfma_workspace(const devis_convT_desc* d) {
   if (!convT_wgrad_ok(d)) return 0;
-  return pw_plan(d->N * d->ID * d->IH * d->IW, d->KD * d->KH * d->KW, (int)d->Cin, (int)d->Cout, (int)d->Cout).total_bytes;
+  const int nz = convT_wide(d) ? (int)((d->Cin / 128) * (d->Cout / 64)) : 1;
+  return pw_plan(d->N * d->ID * d->IH * d->IW, d->KD * d->KH * d->KW, (int)d->Cin, (int)d->Cout, (int)d->Cout, nz).total_bytes;
 }
 
 int convT_wgrad_mfma(const devis_convT_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* ws,
@@ -325,9 +341,11 @@ int convT_wgrad_mfma(const devis_convT_desc* d, const void* x, const void* dy, f
   a.NV = d->N * d->ID * d->IH * d->IW;
   a.bias_side = dbias ? 2 : 0;
   const int T = d->KD * d->KH * d->KW;
-  const PwWgPlan pl = pw_plan(a.NV, T, a.M, a.N, a.N);
+  const int nz = convT_wide(d) ? (int)((d->Cin / 128) * (d->Cout / 64)) : 1;
+  const PwWgPlan pl = pw_plan(a.NV, T, a.M, a.N, a.N, nz);      // partial bytes: the whole [Cin][Cout] weight
   if (!ws || ws_bytes < pl.total_bytes) return DEVIS_ERR_WORKSPACE;
-  return pw_wgrad_launch<PWG_CONVT>(a, pl, a.N, dw, dbias, ws, s);
+  if (nz > 1) { a.ldm = a.M; a.ldn = a.N; a.nms = a.M / 128; a.M = 128; a.N = 64; }
+  return pw_wgrad_launch<PWG_CONVT>(a, pl, (int)d->Cout, dw, dbias, ws, s);
 }
 
 // ---- k2-s2-p0 'down' conv wgrad: dw[co][ci][t] = sum dy_coarse[co] * x_fine[tap t][ci] - the ConvT wgrad GEMM with

@@ -20,6 +20,8 @@ struct RedArgs {
   int64_t total;        // floats of a partial that are summed (multiple of 4)
   int mode;             // RED_CONV3: o = (t*A + co)*B + ci -> dw[(co*cin_real + ci)*T + t], ci < cin_real, T = total/(A*B)
   int A, B, cin_real;   // RED_PW:    o = p*B + mn          -> dw[mn*A + p]   (A = taps T, B = M*N)
+  // RED_PW with channel slabs (nms > 0): mn = (z*msub + m)*nsub + n, z = ns*nms + ms -> row ms*msub + m, column ns*nsub + n
+  int nms = 0, msub = 0, nsub = 0, ntot = 0;
 };
 
 // LANES float4 columns per block x KG = 1024/LANES partial groups.  Small outputs (a 16x16x27 weight is
@@ -85,7 +87,13 @@ k_reduce_partials(RedArgs a) {
       } else {
         const int64_t mn = o % a.B;
         const int p = (int)(o / a.B);
-        a.dw[mn * a.A + p] = sv[j];
+        if (a.nms > 0) {
+          const int n = (int)(mn % a.nsub), m = (int)((mn / a.nsub) % a.msub), z = (int)(mn / ((int64_t)a.nsub * a.msub));
+          const int row = (z % a.nms) * a.msub + m, col = (z / a.nms) * a.nsub + n;
+          a.dw[((int64_t)row * a.ntot + col) * a.A + p] = sv[j];
+        } else {
+          a.dw[mn * a.A + p] = sv[j];
+        }
       }
     }
   } else if (a.dbias) {

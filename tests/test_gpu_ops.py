@@ -62,6 +62,9 @@ CONV_CASES = [
     (3, 128, 0, 256, (16, 16), (3, 3), (1, 1), (1, 1)),
     (8, 32, 0, 64, (128, 128), (3, 3), (1, 1), (1, 1)),
     (8, 32, 0, 32, (128, 128), (3, 3), (1, 1), (1, 1)),
+    # the 2-D nets' first layer (1 input channel; 3 is above) and 2-class head
+    (2, 1, 0, 32, (20, 24), (3, 3), (1, 1), (1, 1)),
+    (2, 32, 0, 2, (16, 24), (1, 1), (1, 1), (0, 0)),
 ]
 
 
@@ -122,7 +125,8 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, prologue):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 16, 8, (3, 4, 5), (2, 2, 2)), (2, 32, 16, (5, 6), (2, 2)), (1, 64, 64, (2, 2, 2), (2, 2, 2))])
+@pytest.mark.parametrize("case", [(2, 16, 8, (3, 4, 5), (2, 2, 2)), (2, 32, 16, (5, 6), (2, 2)), (1, 64, 64, (2, 2, 2), (2, 2, 2)),
+                                  (2, 256, 128, (4, 4), (2, 2)), (1, 512, 256, (4, 8), (2, 2))])   # wide 2-D up-convs: channel slabs
 def test_convT(case, dtype):
     from devis_amd import ops
     n, ci, co, sp, k = case
