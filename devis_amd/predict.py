@@ -56,7 +56,7 @@ def _default_head(backbone, thresholds, want_evidence, want_mne):
 
 
 def sliding_window_infer(x, backbone, thresholds=(), rank: int = 0, world: int = 1, group=None,
-                         want_evidence: bool = False, want_mne: bool = True, patch_fn=None):
+                         want_evidence: bool = False, want_mne: bool = True, patch_fn=None, patch_batch: int = 1):
     """Sharded form of the BraTS val/test forward (predict.py:159-191 + trainUMIS.py:286-290,446-461,521):
     patch i runs on rank i % world, each rank applies the fused inference head to its own
     patches and writes their kept sub-regions into zero-initialised volume maps; the regions are disjoint, so
@@ -64,21 +64,31 @@ def sliding_window_infer(x, backbone, thresholds=(), rank: int = 0, world: int =
 
     Returns dict(pred uint8 (1,240,240,155), u fp32 (1,1,...), mne fp32, umask int16, evidence fp32 (1,K,...))
     with the entries that were asked for.  `patch_fn(patch) -> dict` replaces backbone + head (tests).
+    `patch_batch` > 1 sends that many of a rank's patches through the network as ONE batch (an eighth of the
+    launches at 8).  In eval mode every sample of a batch is computed independently (GroupNorm is per sample,
+    BatchNorm uses its running statistics), so fp32 maps are the same bits as the reference's one-by-one order;
+    in bf16 the kernels' tile shapes and statistics chunks depend on the batch size, so values agree to bf16
+    rounding only - the default stays 1 (the reference's order).
     """
     from .parallel import shard_patches
     run = patch_fn if patch_fn is not None else _default_head(backbone, thresholds, want_evidence, want_mne)
     vol = tuple(x.shape[2:4]) + (155,)
     out = {}
-    for i in shard_patches(len(CROPS), rank, world):
-        maps = run(crop(x, i))
-        dst, src = patch_regions(i)
-        for key, t in maps.items():
-            if t is None:
-                continue
-            if key not in out:
-                lead = tuple(t.shape[:t.dim() - 3])
-                out[key] = torch.zeros(lead + vol, dtype=t.dtype, device=t.device)
-            out[key][(Ellipsis,) + dst] = t[(Ellipsis,) + src]
+    mine = list(shard_patches(len(CROPS), rank, world))
+    pb = max(1, int(patch_batch))
+    for c0 in range(0, len(mine), pb):
+        group_ids = mine[c0:c0 + pb]
+        patches = [crop(x, i) for i in group_ids]
+        maps = run(patches[0] if len(patches) == 1 else torch.cat(patches, dim=0))
+        for j, i in enumerate(group_ids):
+            dst, src = patch_regions(i)
+            for key, t in maps.items():
+                if t is None:
+                    continue
+                if key not in out:
+                    lead = (1,) + tuple(t.shape[1:t.dim() - 3])
+                    out[key] = torch.zeros(lead + vol, dtype=t.dtype, device=t.device)
+                out[key][(Ellipsis,) + dst] = t[j:j + 1][(Ellipsis,) + src]
     if world > 1:
         import torch.distributed as dist
         keys = sorted(out)                       # same order on every rank (every rank owns >= 1 patch iff world <= 8)
