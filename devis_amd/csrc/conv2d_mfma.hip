@@ -235,7 +235,7 @@ k_conv2_mfma(Conv2Args a) {
   if (STATS) {
     __syncthreads();               // every wave is done reading its LDS fragments
     const int chunk = tile % (a.ntw * a.nth);
-    stats_finish<MT>(f0, f1, reinterpret_cast<double*>(smem),
+    stats_finish_dpp<MT>(f0, f1, reinterpret_cast<double*>(smem),
                      a.st.partial + (((size_t)n * a.st.chunks + chunk) * a.Cout + co_base) * 2);
   }
 }

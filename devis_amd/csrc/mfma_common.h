@@ -100,4 +100,36 @@ __device__ __forceinline__ void stats_finish(const float (&f0)[MT][4], const flo
   if (tid < MT * 32) pout[tid] = ((red[tid] + red[MT * 32 + tid]) + red[2 * MT * 32 + tid]) + red[3 * MT * 32 + tid];
 }
 
+// Same contract as stats_finish, cheaper for small tiles: the 16 lanes that share channels (one DPP row) add
+// their fp32 sums with four DPP adds per value (quad swaps, then the half-row and row mirrors: every lane ends
+// with the row total) instead of eight 64-bit cross-lane permutes; the four waves then add up in fp64 through
+// LDS in a fixed order.  At most 16 * NT addends meet in fp32.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);     // row_half_mirror
+  v = dpp_add<0x140>(v);     // row_mirror
+  return v;
+}
+template <int MT>
+__device__ __forceinline__ void stats_finish_dpp(const float (&f0)[MT][4], const float (&f1)[MT][4], double* red, double* pout) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = row16_sum(f0[m][j]), b = row16_sum(f1[m][j]);
+      if (l15 == 0) {
+        red[((wave * MT + m) * 16 + lq * 4 + j) * 2 + 0] = (double)a;
+        red[((wave * MT + m) * 16 + lq * 4 + j) * 2 + 1] = (double)b;
+      }
+    }
+  __syncthreads();
+  if (tid < MT * 32) pout[tid] = ((red[tid] + red[MT * 32 + tid]) + red[2 * MT * 32 + tid]) + red[3 * MT * 32 + tid];
+}
+
 }  // namespace devis

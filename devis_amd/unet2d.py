@@ -40,19 +40,26 @@ class _Run2d:
         if self.taping:
             self.tape.append(e)
 
-    def _bn(self, name, x):
+    def _bn(self, name, x, partials=None):
         return ops.bn_stats(x, self.P[name + ".weight"], self.P[name + ".bias"],
                             self.B[name + ".running_mean"], self.B[name + ".running_var"], self.training,
-                            tracked=self.B[name + ".num_batches_tracked"])
+                            tracked=self.B[name + ".num_batches_tracked"], partials=partials)
+
+    def _conv_stats(self, *a):
+        """conv + the moments of its output for the BatchNorm that follows, gathered in the conv's epilogue
+        when the kernel for this shape can (the MFMA layers in bf16); else the separate pass inside bn_stats."""
+        if not self.training:
+            return ops.conv_fwd(*a), None
+        return ops.conv_fwd(*a, want_stats=True)
 
     def double_conv(self, name, x1, x2=None):
         P = self.P
         w0 = ops.pack_conv_weight(P[name + ".conv.0.weight"], self.dtype)
-        h1 = ops.conv_fwd(x1, x2, w0, P[name + ".conv.0.bias"], C3)
-        st1 = self._bn(name + ".conv.1", h1)
+        h1, part = self._conv_stats(x1, x2, w0, P[name + ".conv.0.bias"], C3)
+        st1 = self._bn(name + ".conv.1", h1, part)
         w3 = ops.pack_conv_weight(P[name + ".conv.3.weight"], self.dtype)
-        h2 = ops.conv_fwd(h1, None, w3, P[name + ".conv.3.bias"], C3, st1[0], st1[1])
-        st2 = self._bn(name + ".conv.4", h2)
+        h2, part = self._conv_stats(h1, None, w3, P[name + ".conv.3.bias"], C3, st1[0], st1[1])
+        st2 = self._bn(name + ".conv.4", h2, part)
         out = ops.affine_act(h2, st2[0], st2[1], relu=True)
         self._push("dc", name, x1, x2, h1, h2, st1, st2, w0, w3)
         return out
@@ -113,9 +120,10 @@ class _Run2d:
             dout, h2, st2[0], st2[1], P[name + ".conv.4.weight"], st2[2], st2[3], 0, True)
         g[name + ".conv.3.weight"], g[name + ".conv.3.bias"] = ops.conv_wgrad(
             h1, None, dh2, C3, P[name + ".conv.3.weight"].shape, st1[0], st1[1])
-        da = ops.conv_dgrad(dh2, w3, C3, h1.shape)[0]
+        # this dgrad feeds bn1's backward: its epilogue leaves the two moments that backward needs
+        da, _, part = ops.conv_dgrad(dh2, w3, C3, h1.shape, norm=(h1, st1[0], st1[1]))
         dh1, g[name + ".conv.1.weight"], g[name + ".conv.1.bias"] = ops.norm_relu_bwd(
-            da, h1, st1[0], st1[1], P[name + ".conv.1.weight"], st1[2], st1[3], 0, True)
+            da, h1, st1[0], st1[1], P[name + ".conv.1.weight"], st1[2], st1[3], 0, True, partials=part)
         g[name + ".conv.0.weight"], g[name + ".conv.0.bias"] = ops.conv_wgrad(
             x1, x2, dh1, C3, P[name + ".conv.0.weight"].shape)
         if not need_dx1:

@@ -314,6 +314,57 @@ def test_conv_epilogue_forward_moments(case, prologue, residual):
         assert rel_err(u, v) < 1e-4
 
 
+STATS2D_CASES = [
+    # (N, C1, C2, Cout, (H, W)): the 2-D MFMA kernels' tile variants, a two-input layer, ragged tiles
+    (2, 32, 0, 32, (16, 16)), (1, 32, 32, 32, (20, 40)), (2, 64, 64, 64, (9, 18)), (3, 128, 0, 256, (16, 16)),
+    (8, 32, 0, 64, (128, 128)),
+]
+
+
+@pytest.mark.parametrize("case", STATS2D_CASES)
+@pytest.mark.parametrize("prologue", [False, True])
+def test_conv2d_epilogue_moments(case, prologue):
+    """2-D 3x3 layers: forward leaves {sum y, sum y^2} of the stored output, dgrad (single-input layers) the
+    norm-backward moments {sum g, sum g*x}; outputs are unchanged by gathering them."""
+    from devis_amd import ops
+    n, c1, c2, co, sp = case
+    g = torch.Generator().manual_seed(13)
+    x1 = cl(torch.randn((n, c1) + sp, generator=g), torch.bfloat16)
+    x2 = cl(torch.randn((n, c2) + sp, generator=g), torch.bfloat16) if c2 else None
+    w = torch.randn((co, c1 + c2, 3, 3), generator=g) * 0.1
+    b = torch.randn((co,), generator=g).cuda()
+    geom = ops.ConvGeom((3, 3), (1, 1), (1, 1))
+    wp = ops.pack_conv_weight(w.cuda(), torch.bfloat16)
+    sc = (torch.rand((n, c1 + c2), generator=g) + 0.5).cuda() if prologue else None
+    sh = (torch.randn((n, c1 + c2), generator=g) * 0.3).cuda() if prologue else None
+    y0 = ops.conv_fwd(x1, x2, wp, b, geom, sc, sh)
+    y, part = ops.conv_fwd(x1, x2, wp, b, geom, sc, sh, want_stats=True)
+    assert part is not None, "this shape must gather statistics in the epilogue"
+    assert torch.equal(y, y0)
+    buf, chunks = part
+    assert buf.shape == (n, chunks, co, 2)
+    yd = y.double().cpu().reshape(n, -1, co)
+    want = torch.stack([yd.sum(1), (yd * yd).sum(1)], dim=-1)
+    got = buf.sum(1).cpu()
+    assert rel_err(got[..., 0], want[..., 0]) < 2e-5
+    assert rel_err(got[..., 1], want[..., 1]) < 2e-5
+    if c2 or prologue:
+        return
+    dy = cl(torch.randn((n, co) + sp, generator=g), torch.bfloat16)
+    scn = (torch.rand((n, c1), generator=g) + 0.5).cuda()
+    shn = (torch.randn((n, c1), generator=g) * 0.3).cuda()
+    dx0, _ = ops.conv_dgrad(dy, wp, geom, x1.shape)
+    dx, _, part = ops.conv_dgrad(dy, wp, geom, x1.shape, norm=(x1, scn, shn))
+    assert part is not None and torch.equal(dx, dx0)
+    got = part[0].sum(1).cpu()
+    xd = x1.double().cpu().reshape(n, -1, c1)
+    gate = torch.addcmul(shn.cpu()[:, None, :], x1.float().cpu().reshape(n, -1, c1), scn.cpu()[:, None, :]) > 0
+    gd = dx.double().cpu().reshape(n, -1, c1) * gate
+    want = torch.stack([gd.sum(1), (gd * xd).sum(1)], dim=-1)
+    assert rel_err(got[..., 0], want[..., 0]) < 5e-5
+    assert rel_err(got[..., 1], want[..., 1]) < 5e-5
+
+
 # 1x1 layers whose dgrad feeds a DeBlock's bn2 backward: endconv (16 -> 4) and DeUpCat.conv1 (2C -> C)
 PW_STATS_CASES = [(2, 16, 4, (8, 8, 16), 0), (1, 32, 16, (4, 8, 16), 0), (2, 64, 32, (4, 4, 16), 0), (2, 16, 4, (32, 32, 32), 0)]
 
