@@ -233,7 +233,7 @@ k_conv3_deep(DeepArgs a) {
   if (STATS) {
     __syncthreads();               // every wave is done reading its LDS fragments
     const int chunk = tile % (a.ntw * a.nth * a.ntd);
-    stats_finish<MT>(f0, f1, reinterpret_cast<double*>(smem),
+    stats_finish_dpp<MT>(f0, f1, reinterpret_cast<double*>(smem),
                      a.st.partial + (((size_t)n * a.st.chunks + chunk) * a.Cout + co_base) * 2);
   }
 }
