@@ -126,7 +126,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # DEVIS_BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank): rehearse the RCCL path on a one-GPU box
+    multi = world > 1 or (os.environ.get("DEVIS_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if os.environ.get("DEVIS_BENCH_PRESTREAM") == "1":
+        from devis_amd.unet3d import _side_stream
+        _side_stream(dev)
+    if multi:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     from devis_amd import TMSU
@@ -140,7 +145,7 @@ def main():
     model = TMSU(args)
     model.train()
     opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=1e-5, module=model)   # trainUMIS.py:1394, one launch
-    reducer = GradientAllReducer(model.parameters(), module=model) if world > 1 else None
+    reducer = GradientAllReducer(model.parameters(), module=model, force=True) if multi else None
     g = torch.Generator().manual_seed(1234 + rank)
     S = a.size
     x = torch.randn((a.batch, 4, S, S, S), generator=g).to(dev)

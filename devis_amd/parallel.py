@@ -54,13 +54,16 @@ class GradientAllReducer:
     buffer) the all-reduce is bucketed and overlapped with backward (FlatGradSync); parameters outside such a
     backbone, and any other model, go through flat buckets built after backward."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, group=None, module=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, group=None, module=None,
+                 force: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force: run the collectives even in a one-rank group (rehearsal of the RCCL path on a one-GPU box)
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.flat_sync = None
         backbone = getattr(module, "backbone", module)
-        if self.world > 1 and backbone is not None and hasattr(backbone, "_grad_sync"):
+        if self.active and backbone is not None and hasattr(backbone, "_grad_sync"):
             self.flat_sync = FlatGradSync(self.world, group)
             backbone._grad_sync = self.flat_sync
             self._backbone = backbone
@@ -81,7 +84,7 @@ class GradientAllReducer:
 
     def all_reduce(self) -> None:
         """Average .grad across ranks (async launch per bucket, then copy back)."""
-        if self.world == 1:
+        if not self.active:
             return
         if self.flat_sync is not None:
             flat = self._backbone.last_flat_grad

@@ -309,7 +309,12 @@ def _side_stream(device):
         return None
     s = _side_streams.get(device.index)
     if s is None:
-        s = _side_streams[device.index] = torch.cuda.Stream(device)
+        # A high-priority stream gets a hardware queue of its own.  A normal-priority one shares the process's few
+        # queues (GPU_MAX_HW_QUEUES = 4) round-robin with every other stream; once RCCL has created its streams it
+        # landed on the main stream's queue and the two serialised (one-rank RCCL rehearsal: 6.31 ms/step against
+        # 5.58 with priority -1; without a process group the two priorities measure the same).
+        prio = int(os.environ.get("DEVIS_WGRAD_STREAM_PRIORITY", "-1"))
+        s = _side_streams[device.index] = torch.cuda.Stream(device, priority=prio)
     return s
 
 
