@@ -102,11 +102,54 @@ def freeze_gc() -> None:
         _gc_frozen = True
 
 
+class LossMeter:
+    """Per-iteration loss lines and the epoch average without a host sync per iteration (the
+    reference calls loss.item() twice per step, trainUMIS.py:257-262).  Each step's loss is copied to its own
+    pinned host slot behind an event; lines are emitted in step order as soon as their event has completed
+    (normally one or two steps late), the rest at flush().  The running sum stays on the device in fp64."""
+
+    def __init__(self, log=print, slots: int = 8):
+        self.log, self.slots = log, slots
+        self.pending = []            # (step, host slot, event)
+        self.free = []
+        self.total = None
+        self.count = 0
+
+    def update(self, step: int, loss: torch.Tensor) -> None:
+        loss = loss.detach()
+        self.total = loss.double() if self.total is None else self.total + loss.double()
+        self.count += 1
+        if self.log is not None:
+            if len(self.pending) >= self.slots:
+                self._emit(block=True)
+            buf, ev = self.free.pop() if self.free else (torch.empty((), dtype=torch.float32).pin_memory(),
+                                                         torch.cuda.Event())
+            buf.copy_(loss.float(), non_blocking=True)
+            ev.record()
+            self.pending.append((step, buf, ev))
+            self._emit(block=False)
+
+    def _emit(self, block: bool) -> None:
+        while self.pending and (block or self.pending[0][2].query()):
+            step, buf, ev = self.pending.pop(0)
+            ev.synchronize()
+            self.log("%d,train_loss:%0.3f" % (step, float(buf)))
+            self.free.append((buf, ev))
+            block = False
+
+    def flush(self) -> float:
+        """Emit what is left; -> the average loss (one sync per epoch)."""
+        while self.pending:
+            self._emit(block=True)
+        return float(self.total.item() / self.count) if self.count else 0.0
+
+
 def train(args, model, optimizer, epoch, train_loader, reducer=None, log=print):
     """One epoch; same order of operations as trainUMIS.py:239-263.  `reducer` (devis_amd.parallel)
-    averages gradients across ranks.  The per-iteration loss print is kept (it is a host sync)."""
+    averages gradients across ranks.  The per-iteration loss lines are kept, in order, but are printed
+    through LossMeter: the launch thread never waits for the GPU inside the loop."""
     model.train()
-    meter = AverageMeter()
+    meter = LossMeter(log)
     step = 0
     freeze_gc()
     for data in train_loader:
@@ -122,11 +165,8 @@ def train(args, model, optimizer, epoch, train_loader, reducer=None, log=print):
         if reducer is not None:
             reducer.all_reduce()
         optimizer.step()
-        val = loss.item()
-        if log is not None:
-            log("%d,train_loss:%0.3f" % (step, val))
-        meter.update(val)
-    return meter.avg
+        meter.update(step, loss)
+    return meter.flush()
 
 
 def predict_volume(model, x, dataset, thresholds=()):

@@ -83,3 +83,30 @@ def test_fused_adam_on_the_backbone_reads_the_flat_gradient():
         else:
             assert torch.equal(sd0[k], sd1[k]), k             # num_batches_tracked
             assert int(sd0[k]) == 1
+
+
+def test_train_loop_logs_every_step_without_per_step_sync():
+    """devis_amd.train.train(): one line per iteration, in order, with the same values as loss.item() gives, and the
+    epoch average of those losses (LossMeter defers the host copies instead of syncing every step)."""
+    from devis_amd import TMSU
+    from devis_amd.optim import FusedAdam
+    from devis_amd.train import train
+    from tests.util import brats_args
+    args = brats_args(compute_dtype=torch.bfloat16)
+    args.lr, args.mode = 0.002, 'train'
+    g = torch.Generator().manual_seed(3)
+    data = [(torch.randn((1, 4, 32, 32, 32), generator=g), torch.randint(0, 4, (1, 32, 32, 32), generator=g))
+            for _ in range(12)]
+
+    def run(log):
+        torch.manual_seed(0)
+        m = TMSU(args)
+        opt = FusedAdam(m.parameters(), lr=args.lr, weight_decay=1e-5, module=m)
+        return train(args, m, opt, 25, data, log=log)
+
+    lines = []
+    avg = run(lines.append)
+    assert [int(l.split(",")[0]) for l in lines] == list(range(1, 13))
+    vals = [float(l.split(":")[1]) for l in lines]
+    assert abs(avg - sum(vals) / 12) < 2e-3          # the lines are rounded to 3 decimals
+    assert abs(run(None) - avg) < 1e-6               # no logging: same training, same average
