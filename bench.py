@@ -81,6 +81,15 @@ def kernel_probe(batch, size, dtype):
     res["conv3d_fwd_c16"] = (timeit(lambda: ops.conv_fwd(x, None, wp, b, G3, sc, sh)), flops, vox * 16 * esz * 2)
     res["conv3d_dgrad_c16"] = (timeit(lambda: ops.conv_dgrad(dy, wp, G3, x.shape)), flops, vox * 16 * esz * 2)
     res["conv3d_wgrad_c16"] = (timeit(lambda: ops.conv_wgrad(x, None, dy, G3, w.shape, sc, sh)), flops, vox * 16 * esz * 2)
+    # the fused evidential head + loss (north_star's second roofline): channels-last K=4 logits, int64 labels.
+    # Algorithmic bytes: forward reads K*s + 8 and writes the fp32 evidence the train mode returns
+    # (K*4); backward re-reads K*s + 8 and writes K*s.  FLOP column: 0 (transcendental-bound).
+    z = torch.randn((batch, size, size, size, 4), generator=g).to(dtype).to(dev)
+    lab = torch.randint(0, 4, (batch, size, size, size), generator=g).to(dev)
+    one = torch.ones((), device=dev)
+    scal, _, _ = ops.evid_loss_fwd(z, True, lab, 0.5, True)
+    res["evid_head_loss_fwd"] = (timeit(lambda: ops.evid_loss_fwd(z, True, lab, 0.5, True)), 0.0, vox * (4 * esz + 8 + 16))
+    res["evid_head_loss_bwd"] = (timeit(lambda: ops.evid_loss_bwd(z, True, lab, 0.5, scal, one)), 0.0, vox * (4 * esz + 8 + 4 * esz))
     return res
 
 

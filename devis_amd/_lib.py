@@ -96,6 +96,7 @@ SIGNATURES = {
     "devis_add": (_I, [_P, _P, _P, _I64, _I, _P]),
     "devis_maxpool2d_fwd": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "devis_maxpool2d_bwd": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),
+    "devis_maxpool2d_bwd_add": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "devis_evid_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "devis_evid_loss_fwd": (_I, [_P, _I64, _I64, _I64, _I, _P, _I, _I64, _I64, _I64, _F, _P, _P, _P, _P, _SZ, _P]),
     "devis_evid_loss_bwd": (_I, [_P, _I64, _I64, _I64, _I, _P, _I, _I64, _I64, _I64, _F, _P, _P, _P, _P, _P, _P, _P]),

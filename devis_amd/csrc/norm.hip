@@ -554,6 +554,90 @@ k_maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __re
   st(dx + i, g);
 }
 
+// bf16, C % 8 == 0: one thread per (2x2 cell, 8-channel piece), 16-byte accesses
+__global__ void __launch_bounds__(256)
+k_maxpool_fwd_v8(const bf16* __restrict__ x, bf16* __restrict__ y, uint8_t* __restrict__ idx, int N, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2, PC = C / 8;
+  const int64_t total = (int64_t)N * OH * OW * PC;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int pc = (int)(i % PC);
+  int64_t r = i / PC;
+  const int ow = (int)(r % OW); r /= OW;
+  const int oh = (int)(r % OH);
+  const int n = (int)(r / OH);
+  float best[8];
+  unsigned bi[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {   // scan order (kh, kw); strictly-greater keeps the first maximum, NaN propagates
+    const uint4 t = *reinterpret_cast<const uint4*>(x + ((size_t)(n * H + oh * 2 + (k >> 1)) * W + ow * 2 + (k & 1)) * C + pc * 8);
+    const unsigned w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (j & 1) ? __uint_as_float(w4[j >> 1] & 0xffff0000u) : __uint_as_float(w4[j >> 1] << 16);
+      if (k == 0 || v > best[j] || v != v) { best[j] = v; bi[j] = (unsigned)k; }
+    }
+  }
+  union { bf16 h[8]; uint4 u; } o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.h[j] = (bf16)best[j];
+  const size_t ob = ((size_t)(n * OH + oh) * OW + ow) * C + pc * 8;
+  *reinterpret_cast<uint4*>(y + ob) = o.u;
+  uint2 ib;
+  ib.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+  ib.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+  *reinterpret_cast<uint2*>(idx + ob) = ib;
+}
+
+// dx = scatter(dy by idx) (+ skip): the gradient of the pooled branch and the skip branch's gradient in one pass
+__global__ void __launch_bounds__(256)
+k_maxpool_bwd_v8(const bf16* __restrict__ dy, const uint8_t* __restrict__ idx, const bf16* __restrict__ skip,
+                 bf16* __restrict__ dx, int N, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2, CH = (H + 1) / 2, CW = (W + 1) / 2, PC = C / 8;
+  const int64_t total = (int64_t)N * CH * CW * PC;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int pc = (int)(i % PC);
+  int64_t r = i / PC;
+  const int cw = (int)(r % CW); r /= CW;
+  const int ch = (int)(r % CH);
+  const int n = (int)(r / CH);
+  float g[8];
+  unsigned bi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { g[j] = 0.f; bi[j] = 4u; }
+  if (ch < OH && cw < OW) {
+    const size_t ob = ((size_t)(n * OH + ch) * OW + cw) * C + pc * 8;
+    const uint4 t = *reinterpret_cast<const uint4*>(dy + ob);
+    const uint2 ib = *reinterpret_cast<const uint2*>(idx + ob);
+    const unsigned w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      g[j] = (j & 1) ? __uint_as_float(w4[j >> 1] & 0xffff0000u) : __uint_as_float(w4[j >> 1] << 16);
+      bi[j] = ((j < 4 ? ib.x : ib.y) >> (8 * (j & 3))) & 0xffu;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int h = ch * 2 + (k >> 1), w = cw * 2 + (k & 1);
+    if (h >= H || w >= W) continue;
+    const size_t xb = ((size_t)(n * H + h) * W + w) * C + pc * 8;
+    float sk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sk[j] = 0.f;
+    if (skip) {
+      const uint4 t = *reinterpret_cast<const uint4*>(skip + xb);
+      const unsigned w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sk[j] = (j & 1) ? __uint_as_float(w4[j >> 1] & 0xffff0000u) : __uint_as_float(w4[j >> 1] << 16);
+    }
+    union { bf16 h8[8]; uint4 u; } o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.h8[j] = (bf16)((bi[j] == (unsigned)k ? g[j] : 0.f) + sk[j]);
+    *reinterpret_cast<uint4*>(dx + xb) = o.u;
+  }
+}
+
 static inline bool vec_ok(int64_t C, int dtype) {
   const int vn = dtype == DEVIS_F32 ? 4 : 8;
   if (C % vn) return false;
@@ -743,15 +827,35 @@ int devis_add(const void* a, const void* b, void* z, int64_t n, int dtype, void*
 int devis_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int64_t N, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
   if (!x || !y || !idx || N <= 0 || H < 2 || W < 2 || C <= 0) return DEVIS_ERR_BAD_ARG;
   const int64_t total = N * (H / 2) * (W / 2) * C;
+  if (dtype == DEVIS_BF16 && C % 8 == 0 && N * H * W < ((int64_t)1 << 31) && C < ((int64_t)1 << 31)) {
+    hipLaunchKernelGGL(k_maxpool_fwd_v8, dim3((unsigned)cdiv(total / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (bf16*)y, idx, (int)N, (int)H, (int)W, (int)C);
+    return launch_status();
+  }
   DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_maxpool_fwd<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, idx, N, H, W, C));
   return launch_status();
 }
 
-int devis_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int64_t N, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+int devis_maxpool2d_bwd_add(const void* dy, const uint8_t* idx, const void* skip, void* dx, int64_t N, int64_t H, int64_t W,
+                            int64_t C, int dtype, void* stream) {
   if (!dy || !dx || !idx || N <= 0 || H < 2 || W < 2 || C <= 0) return DEVIS_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
   const int64_t total = N * H * W * C;
-  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, idx, (T*)dx, N, H, W, C));
+  if (dtype == DEVIS_BF16 && C % 8 == 0 && N * H * W < ((int64_t)1 << 31) && C < ((int64_t)1 << 31)) {
+    const int64_t cells = N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    hipLaunchKernelGGL(k_maxpool_bwd_v8, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, s, (const bf16*)dy, idx,
+                       (const bf16*)skip, (bf16*)dx, (int)N, (int)H, (int)W, (int)C);
+    return launch_status();
+  }
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const T*)dy, idx, (T*)dx, N, H, W, C));
+  int rc = launch_status();
+  if (rc || !skip) return rc;
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_add<T>, dim3(ew_grid(total)), dim3(256), 0, s, (const T*)dx, (const T*)skip, (T*)dx, total));
   return launch_status();
+}
+
+int devis_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int64_t N, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+  return devis_maxpool2d_bwd_add(dy, idx, nullptr, dx, N, H, W, C, dtype, stream);
 }
 
 }  // extern "C"

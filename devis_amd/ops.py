@@ -604,11 +604,15 @@ def maxpool2d_fwd(x: Tensor):
     return y, idx
 
 
-def maxpool2d_bwd(dy: Tensor, idx: Tensor, x_shape) -> Tensor:
-    _need_cuda(dy, idx)
+def maxpool2d_bwd(dy: Tensor, idx: Tensor, x_shape, skip: Optional[Tensor] = None) -> Tensor:
+    """-> gradient of the pooled tensor's input (+ `skip`, the gradient arriving through the skip connection)."""
+    _need_cuda(dy, idx, skip)
     n, h, w, c = x_shape
+    if skip is not None and (tuple(skip.shape) != tuple(x_shape) or skip.dtype != dy.dtype):
+        raise _lib.DevisError("maxpool_bwd: skip gradient must have the input's shape and dtype")
     dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
-    check(_lib.load().devis_maxpool2d_bwd(_p(dy), _p(idx), _p(dx), n, h, w, c, dt_code(dy.dtype), _stream()), "maxpool_bwd")
+    check(_lib.load().devis_maxpool2d_bwd_add(_p(dy), _p(idx), _p(skip), _p(dx), n, h, w, c, dt_code(dy.dtype), _stream()),
+          "maxpool_bwd")
     return dx
 
 

@@ -140,9 +140,9 @@ class _Run2d:
         _, (h, w) = self.tape.pop()
         return d[:, :h, :w, :].contiguous() if (d.shape[1] != h or d.shape[2] != w) else d
 
-    def _pool_bwd(self, dy):
+    def _pool_bwd(self, dy, skip):
         _, idx, shape = self.tape.pop()
-        return ops.maxpool2d_bwd(dy, idx, shape)
+        return ops.maxpool2d_bwd(dy, idx, shape, skip)
 
     def backward(self, dlogits, need_dx):
         _, c9, wp = self.tape.pop()
@@ -161,13 +161,13 @@ class _Run2d:
         a, b = self._dc_bwd(d)                         # conv6: (c4, up6 padded)
         dc4, d = a, self._up_bwd(self._pad_bwd(b))
         d, _ = self._dc_bwd(d)                         # conv5
-        d = ops.add(self._pool_bwd(d), dc4)
+        d = self._pool_bwd(d, dc4)
         d, _ = self._dc_bwd(d)                         # conv4
-        d = ops.add(self._pool_bwd(d), dc3)
+        d = self._pool_bwd(d, dc3)
         d, _ = self._dc_bwd(d)                         # conv3
-        d = ops.add(self._pool_bwd(d), dc2)
+        d = self._pool_bwd(d, dc2)
         d, _ = self._dc_bwd(d)                         # conv2
-        d = ops.add(self._pool_bwd(d), dc1)
+        d = self._pool_bwd(d, dc1)
         d, _ = self._dc_bwd(d, need_dx)                # conv1
         return d
 

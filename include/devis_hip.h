@@ -223,6 +223,11 @@ int devis_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int64_t N, int64_t
                         int dtype, void* stream);
 int devis_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int64_t N, int64_t H, int64_t W,
                         int64_t C, int dtype, void* stream);
+/* devis_maxpool2d_bwd plus the skip branch's gradient in the same pass: dx = scatter(dy by idx) + skip (skip may
+ * be NULL).  Replaces the autograd accumulation of the two gradients that reach c1..c4 in Unet2D.forward
+ * (models/lib/UNet2DZoo.py:131-141: each c_k feeds both the pooling and a merge). */
+int devis_maxpool2d_bwd_add(const void* dy, const uint8_t* idx, const void* skip, void* dx, int64_t N, int64_t H,
+                            int64_t W, int64_t C, int dtype, void* stream);
 
 /* -------------------------------------------------- evidential head/loss -- */
 /* Element (n, v, k) of `logits` lives at logits[n*sN + v*sV + k*sK] (element strides), so both

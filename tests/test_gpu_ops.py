@@ -233,6 +233,19 @@ def test_maxpool(shape, dtype):
     dx = ops.maxpool2d_bwd(cl(dy, torch.float32).to(dtype), idx, xg.shape)
     ref = xr.grad if dtype == torch.float32 else xr.grad.bfloat16().float()
     assert rel_err(uncl(dx), ref) < (1e-7 if dtype == torch.float32 else 1e-2)
+    # with the skip connection's gradient added in the same pass (odd sizes: the last row / column gets skip only)
+    skip = torch.randn(shape, generator=g)
+    if dtype == torch.bfloat16:
+        skip = skip.bfloat16().float()
+    dxs = ops.maxpool2d_bwd(cl(dy, torch.float32).to(dtype), idx, xg.shape, cl(skip, dtype))
+    dyq = dy if dtype == torch.float32 else dy.bfloat16().float()
+    xq = x.clone().requires_grad_(True)
+    F.max_pool2d(xq, 2).backward(dyq)
+    want = xq.grad + skip
+    if dtype == torch.bfloat16:
+        assert torch.equal(uncl(dxs), want.bfloat16().float())       # one rounding, like bf16(pool grad) + skip
+    else:
+        assert rel_err(uncl(dxs), want) < 1e-7
 
 
 def test_layout_roundtrip_and_add():
