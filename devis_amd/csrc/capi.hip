@@ -3,6 +3,8 @@
 #include "common.h"
 #include "mfma_common.h"
 
+#include <stdlib.h>
+
 namespace devis {
 // conv_direct.hip
 int conv_fwd_direct(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
@@ -40,6 +42,8 @@ int first2d_wgrad(const devis_conv_desc*, const void*, const void*, float*, floa
 int head_fwd(const devis_conv_desc*, const void*, const void*, const float*, const void*, void*, hipStream_t);
 int head_dgrad(const devis_conv_desc*, const void*, const void*, const void*, void*, const StatsArgs*, int64_t*, hipStream_t);
 int conv3s2_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
+// conv_s2_dgrad.hip: the same layers with the coarse tile and the weights staged in LDS
+int conv3s2_dgrad_lds(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
 size_t conv1_wgrad_mfma_workspace(const devis_conv_desc*);
 int conv1_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, float*, float*, void*, size_t, hipStream_t);
 size_t conv_wgrad_mfma_workspace(const devis_conv_desc*);
@@ -154,6 +158,11 @@ int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void*
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = conv1_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;     // statistics only come from the MFMA kernels
+  static const bool no_s2lds = getenv("DEVIS_NO_S2LDS") != nullptr;
+  if (!no_s2lds) {
+    rc = conv3s2_dgrad_lds(d, dy, w_dgrad, residual, dx1, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  }
   rc = conv3s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = conv2s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);

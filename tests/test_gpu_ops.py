@@ -43,6 +43,8 @@ CONV_CASES = [
     (1, 16, 0, 32, (8, 8, 32), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (2, 32, 0, 64, (8, 8, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (1, 64, 0, 128, (4, 8, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (1, 16, 0, 32, (5, 7, 9), (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # odd sizes: ragged parity classes in the dgrad
+    (1, 32, 0, 64, (6, 10, 36), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     # 1x1 layers (gather-GEMM kernels in bf16): DeUpCat conv1 / conv3 (virtual concat) / endconv shapes
     (1, 128, 0, 64, (4, 4, 16), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (2, 64, 64, 64, (3, 5, 18), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
