@@ -326,6 +326,8 @@ int conv3_c16_march(const devis_conv_desc* d, const void* x, const void* w, cons
 
 int conv3_deep(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
                const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
+int conv3_deep2(const devis_conv_desc*, const void*, const void*, const float*, const float*, const float*, const void*, void*,
+                const StatsArgs*, int64_t*, hipStream_t);
 
 int conv3_c32_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
                     const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
@@ -352,6 +354,9 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
     static const bool no_march = getenv("DEVIS_NO_MARCH") != nullptr;
     if (!no_march && co == 16 && (ci == 16 || (ci == 4 && !sc))) return conv3_c16_march(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
     static const bool no_deep = getenv("DEVIS_NO_DEEP") != nullptr;
+    // DEVIS_DEEP2: bit 0 = 64-channel layers, bit 1 = 128-channel layers on conv_deep64.hip's kernel (default: 64 only)
+    static const int deep2 = getenv("DEVIS_DEEP2") ? atoi(getenv("DEVIS_DEEP2")) : 1;
+    if (!no_deep && ci == co && ((ci == 64 && (deep2 & 1)) || (ci == 128 && (deep2 & 2)))) return conv3_deep2(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
     if (!no_deep && ci == co && (ci == 64 || ci == 128)) return conv3_deep(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
     if (ci == 16 && co == 16) return CONV3(16, 16, 8, 8, 16, 1);
     if (ci == 4 && co == 16 && !sc) return CONV3(16, 16, 8, 8, 16, 1);
