@@ -22,13 +22,13 @@ __device__ __forceinline__ float dsoftplus_f(float z) {
 // Training-path variants on the hardware exp/log/rcp (1 ulp): |error| < 1e-7 + 1e-6 * value, far inside the
 // parity bars; the inference head keeps the libm forms above (its argmax / threshold masks are bit-exact).
 __device__ __forceinline__ float softplus_fast(float z) {
-  const float t = __expf(fminf(z, 20.f));
+  const float t = __builtin_amdgcn_exp2f(fminf(z, 20.f) * 1.4426950408889634f);
   const float small = t * (1.f - t * (0.5f - t * 0.33333333f));      // log1p(t), t < 0.01
-  const float big = __logf(1.f + t);
+  const float big = __builtin_amdgcn_logf(1.f + t) * 0.69314718055994531f;   // 1 + t >= 1: no denormal rescaling needed
   return z > 20.f ? z : (t < 0.01f ? small : big);
 }
 __device__ __forceinline__ float dsoftplus_fast(float z) {
-  const float t = __expf(fminf(z, 20.f));
+  const float t = __builtin_amdgcn_exp2f(fminf(z, 20.f) * 1.4426950408889634f);
   return z > 20.f ? 1.f : t * __builtin_amdgcn_rcpf(t + 1.f);
 }
 
@@ -38,7 +38,10 @@ __device__ __forceinline__ float dsoftplus_fast(float z) {
 // then the asymptotic series at X >= 6 (truncation < 1e-9).  Hardware rcp/log (1 ulp) are used: their
 // error is below the fp32 rounding of the terms they feed.
 __device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float log_f(float x) { return __logf(x); }
+// raw v_log_f32 (log2) * ln 2: every argument here is >= 1, so __logf's denormal-range rescaling (five extra
+// instructions per call) is dead weight in kernels whose limit is the vector ALU
+__device__ __forceinline__ float log_f(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+__device__ __forceinline__ float exp_f(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 // psi(x) and ln Gamma(x) together (they share P, 1/X and log X)
 __device__ __forceinline__ void psi_lgamma_f(float x, float& psi, float& lg) {
@@ -54,6 +57,27 @@ __device__ __forceinline__ void psi_lgamma_f(float x, float& psi, float& lg) {
   const float lser = xi * (8.3333333333e-2f - x2 * (2.7777777778e-3f - x2 * (7.9365079365e-4f - x2 * 5.9523809524e-4f)));
   psi = (lx - 0.5f * xi - pser) - (small ? num * rcp_f(P) : 0.f);
   lg = ((X - 0.5f) * lx - X + 0.91893853320467f + lser) - (small ? log_f(P) : 0.f);
+}
+// two arguments at once: the polynomial parts become packed fp32 instructions (v_pk_mul/fma_f32: two lanes' worth
+// of FMAs per issue on gfx950); the kernels below are VALU-bound, not HBM-bound, so this is where their time is
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void psi_lgamma_f2(f32x2 x, f32x2& psi, f32x2& lg) {
+  const bool s0 = x.x < 6.f, s1 = x.y < 6.f;
+  const f32x2 xs = {s0 ? x.x : 1.f, s1 ? x.y : 1.f};
+  const f32x2 a0 = xs * (xs + 1.f), a1 = (xs + 2.f) * (xs + 3.f), a2 = (xs + 4.f) * (xs + 5.f);
+  const f32x2 b0 = 2.f * xs + 1.f, b1 = 2.f * xs + 5.f, b2 = 2.f * xs + 9.f;
+  const f32x2 a12 = a1 * a2;
+  const f32x2 P = a0 * a12;
+  const f32x2 num = b0 * a12 + (b1 * (a0 * a2) + b2 * (a0 * a1));
+  const f32x2 X = {s0 ? x.x + 6.f : x.x, s1 ? x.y + 6.f : x.y};
+  const f32x2 xi = {rcp_f(X.x), rcp_f(X.y)}, x2 = xi * xi, lx = {log_f(X.x), log_f(X.y)};
+  const f32x2 pser = x2 * (8.3333333333e-2f - x2 * (8.3333333333e-3f - x2 * (3.9682539683e-3f - x2 * (4.1666666667e-3f - x2 * 7.5757575758e-3f))));
+  const f32x2 lser = xi * (8.3333333333e-2f - x2 * (2.7777777778e-3f - x2 * (7.9365079365e-4f - x2 * 5.9523809524e-4f)));
+  const f32x2 rP = {rcp_f(P.x), rcp_f(P.y)}, lP = {log_f(P.x), log_f(P.y)};
+  const f32x2 corr_p = num * rP;
+  const f32x2 p0 = lx - 0.5f * xi - pser, l0 = (X - 0.5f) * lx - X + 0.91893853320467f + lser;
+  psi = (f32x2){p0.x - (s0 ? corr_p.x : 0.f), p0.y - (s1 ? corr_p.y : 0.f)};
+  lg = (f32x2){l0.x - (s0 ? lP.x : 0.f), l0.y - (s1 ? lP.y : 0.f)};
 }
 __device__ __forceinline__ float digamma_f(float x) {
   const bool small = x < 6.f;
@@ -214,16 +238,33 @@ k_crit_fwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
 #pragma unroll
       for (int k = 0; k < EV_MAXK; ++k) if (k == y) { e_y = e[k]; a_y = al[k]; }
       const float St = S - e_y;            // strength of alpha~ (label class reset to 1)
-      float psiSt, lgSt;
-      psi_lgamma_f(St, psiSt, lgSt);
+      float psiSt, lgSt, psiS4 = 0.f, psiAy4 = 0.f;
       float sum_lg = 0.f, kl_sum = 0.f;
+      if (KT == 4 && (KIND == CRIT_DCE || KIND == CRIT_CE || KIND == CRIT_DCEU)) {
+        // K = 4: the four classes as two packed pairs, (St, S) as a third; psi(alpha_y) is one of the class values
+        f32x2 ps01, lg01, ps23, lg23, psS, lgS;
+        psi_lgamma_f2((f32x2){al[0], al[1]}, ps01, lg01);
+        psi_lgamma_f2((f32x2){al[2], al[3]}, ps23, lg23);
+        psi_lgamma_f2((f32x2){St, S}, psS, lgS);
+        psiSt = psS.x; lgSt = lgS.x; psiS4 = psS.y;
+        const float ps[4] = {ps01.x, ps01.y, ps23.x, ps23.y}, lgv[4] = {lg01.x, lg01.y, lg23.x, lg23.y};
 #pragma unroll
-      for (int k = 0; k < EV_MAXK; ++k) {
-        if (k < K && k != y) {
-          float ps, lg;
-          psi_lgamma_f(al[k], ps, lg);
-          sum_lg += lg;
-          kl_sum = fmaf(e[k], ps - psiSt, kl_sum);
+        for (int k = 0; k < 4; ++k) {
+          const bool lab = k == y;
+          sum_lg += lab ? 0.f : lgv[k];
+          kl_sum = lab ? kl_sum : fmaf(e[k], ps[k] - psiSt, kl_sum);
+          psiAy4 = lab ? ps[k] : psiAy4;
+        }
+      } else {
+        psi_lgamma_f(St, psiSt, lgSt);
+#pragma unroll
+        for (int k = 0; k < EV_MAXK; ++k) {
+          if (k < K && k != y) {
+            float ps, lg;
+            psi_lgamma_f(al[k], ps, lg);
+            sum_lg += lg;
+            kl_sum = fmaf(e[k], ps - psiSt, kl_sum);
+          }
         }
       }
       const float kl = lgSt - sum_lg - lgK + kl_sum;
@@ -241,7 +282,8 @@ k_crit_fwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
         }
         pv = (A + B) + p.lambda * kl;
       } else {
-        pv = fmaf(p.lambda, kl, digamma_f(S) - digamma_f(a_y));
+        if (KT == 4) pv = fmaf(p.lambda, kl, psiS4 - psiAy4);
+        else pv = fmaf(p.lambda, kl, digamma_f(S) - digamma_f(a_y));
       }
       if (KIND == CRIT_DCE) {
 #pragma unroll
