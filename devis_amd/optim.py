@@ -55,6 +55,7 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self._own_grad = None
+        self._own_views = None
         self.step_count = 0
 
     # ---- torch.optim.Optimizer surface used by the reference's loop
@@ -79,12 +80,17 @@ class FusedAdam:
         if self._own_grad is None:
             self._own_grad = torch.empty_like(self.flat_param)
         g = self._own_grad
-        for p, o in self._layout:
-            dst = g[o:o + p.numel()].view(p.shape)
+        if self._own_views is None:
+            self._own_views = [g[o:o + p.numel()].view(p.shape) for p, o in self._layout]
+        dsts, srcs = [], []
+        for (p, _), dst in zip(self._layout, self._own_views):
             if p.grad is None:
                 dst.zero_()
             else:
-                dst.copy_(p.grad)
+                dsts.append(dst)
+                srcs.append(p.grad)
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)          # one multi-tensor launch instead of one copy per parameter
         return g
 
     @torch.no_grad()
