@@ -9,6 +9,8 @@
 #include "common.h"
 #include "mfma_common.h"
 
+#include <stdlib.h>
+
 namespace devis {
 
 enum { PW_CONV1 = 0, PW_CONVT_FWD = 1, PW_CONVT_DGRAD = 2, PW_S2_DGRAD = 3, PW_DOWN_DGRAD = 4 };
@@ -370,7 +372,16 @@ int conv2s2_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_d
 }
 
 // ---- ConvTranspose (kernel == stride) forward and dgrad
+// gemm_convt.hip: the wide 2-D layers
+int convT_fwd_gemm(const devis_convT_desc*, const void*, const void*, const float*, void*, hipStream_t);
+int convT_dgrad_gemm(const devis_convT_desc*, const void*, const void*, void*, hipStream_t);
+static bool convt_gemm_on() { static const bool off = getenv("DEVIS_NO_CONVT_GEMM") != nullptr; return !off; }
+
 int convT_fwd_mfma(const devis_convT_desc* d, const void* x, const void* w, const float* bias, void* y, hipStream_t s) {
+  if (convt_gemm_on()) {
+    const int rc = convT_fwd_gemm(d, x, w, bias, y, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  }
   if (d->dtype != DEVIS_BF16 || d->Cin % 8 || d->Cout % 4) return DEVIS_ERR_UNSUPPORTED;
   if (!small_enough(d->N * d->ID * d->IH * d->IW * d->KD * d->KH * d->KW)) return DEVIS_ERR_UNSUPPORTED;
   PwArgs a = {};
@@ -385,6 +396,10 @@ int convT_fwd_mfma(const devis_convT_desc* d, const void* x, const void* w, cons
 
 // w_t: [Cin][T*Cout] = devis_repack_conv_weight_dgrad(packed convT weight viewed as [T*Cout][1][Cin])
 int convT_dgrad_mfma(const devis_convT_desc* d, const void* dy, const void* w_t, void* dx, hipStream_t s) {
+  if (convt_gemm_on()) {
+    const int rc = convT_dgrad_gemm(d, dy, w_t, dx, s);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  }
   if (!w_t || d->dtype != DEVIS_BF16 || d->Cout % 8 || d->Cin % 4) return DEVIS_ERR_UNSUPPORTED;
   if (!small_enough(d->N * d->ID * d->IH * d->IW * d->KD * d->KH * d->KW)) return DEVIS_ERR_UNSUPPORTED;
   PwArgs a = {};

@@ -128,7 +128,9 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, prologue):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(2, 16, 8, (3, 4, 5), (2, 2, 2)), (2, 32, 16, (5, 6), (2, 2)), (1, 64, 64, (2, 2, 2), (2, 2, 2)),
-                                  (2, 256, 128, (4, 4), (2, 2)), (1, 512, 256, (4, 8), (2, 2))])   # wide 2-D up-convs: channel slabs
+                                  (2, 256, 128, (4, 4), (2, 2)), (1, 512, 256, (4, 8), (2, 2)),    # wide 2-D up-convs: channel slabs
+                                  (5, 256, 128, (16, 16), (2, 2)), (3, 128, 64, (20, 24), (2, 2)),  # ... on the GEMM kernel (>= 1024 pixels)
+                                  (2, 64, 32, (24, 24), (2, 2))])                                   # (dgrad only: K = 4*32)
 def test_convT(case, dtype):
     from devis_amd import ops
     n, ci, co, sp, k = case
