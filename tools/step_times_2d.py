@@ -34,5 +34,5 @@ for _ in range(a.steps):
     l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 px = a.batch * a.size * a.size
-print("Unet2D(1,2) B=%d %dx%d %s: %.2f ms/step, %.1f M px/s, %.1f TFLOP/s, loss %.4f"
+print("Unet2D(1,2) B=%d %dx%d %s: %.2f ms/step, %.1f M px/s, %.1f TFLOP/s, loss %.7f"
       % (a.batch, a.size, a.size, a.dtype, dt * 1e3, px / dt / 1e6, 3 * 367296 * px / dt / 1e12, l.item()))
