@@ -3,7 +3,9 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+# packed fp32 VALU ops are off: v_pk_fma_f32 gave run-to-run different low lanes when kernels of another stream
+# shared the CU; none of these kernels is VALU-bound enough to miss them
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops"
 mkdir -p build
 pids=()
 for f in layout conv_direct conv_mfma conv_march conv_march32 conv_deep conv_deep64 conv2d_mfma conv_s2_dgrad conv_thin conv_wgrad_mfma conv_wgrad_march pointwise_mfma gemm_convt head1x1 pointwise_wgrad_mfma norm attgate evid evalmaps optim capi; do

@@ -113,27 +113,42 @@ class _Run2d:
         return out
 
     # ------------------------------------------------------------ backward
+    def _wg(self, fn, *args, **kw):
+        """A weight-gradient call on the side stream (see unet3d._Run._wg): nothing on backward's critical path
+        reads it, and the deep 16x16 / 32x32 layers leave most of the chip idle for it."""
+        side = self.side
+        if side is None:
+            return fn(*args, **kw)
+        ev = self._events[self._nev % len(self._events)]
+        self._nev += 1
+        ev.record()
+        side.wait_event(ev)
+        with ops.stream_override(side):
+            out = fn(*args, slot="ws_side", **kw)
+        self._keep.append(args)
+        return out
+
     def _dc_bwd(self, dout, need_dx1=True):
         _, name, x1, x2, h1, h2, st1, st2, w0, w3 = self.tape.pop()
         g, P = self.grads, self.P
         dh2, g[name + ".conv.4.weight"], g[name + ".conv.4.bias"] = ops.norm_relu_bwd(
             dout, h2, st2[0], st2[1], P[name + ".conv.4.weight"], st2[2], st2[3], 0, True)
-        g[name + ".conv.3.weight"], g[name + ".conv.3.bias"] = ops.conv_wgrad(
-            h1, None, dh2, C3, P[name + ".conv.3.weight"].shape, st1[0], st1[1])
+        g[name + ".conv.3.weight"], g[name + ".conv.3.bias"] = self._wg(
+            ops.conv_wgrad, h1, None, dh2, C3, P[name + ".conv.3.weight"].shape, st1[0], st1[1])
         # this dgrad feeds bn1's backward: its epilogue leaves the two moments that backward needs
         da, _, part = ops.conv_dgrad(dh2, w3, C3, h1.shape, norm=(h1, st1[0], st1[1]))
         dh1, g[name + ".conv.1.weight"], g[name + ".conv.1.bias"] = ops.norm_relu_bwd(
             da, h1, st1[0], st1[1], P[name + ".conv.1.weight"], st1[2], st1[3], 0, True, partials=part)
-        g[name + ".conv.0.weight"], g[name + ".conv.0.bias"] = ops.conv_wgrad(
-            x1, x2, dh1, C3, P[name + ".conv.0.weight"].shape)
+        g[name + ".conv.0.weight"], g[name + ".conv.0.bias"] = self._wg(
+            ops.conv_wgrad, x1, x2, dh1, C3, P[name + ".conv.0.weight"].shape)
         if not need_dx1:
             return None, None
         return ops.conv_dgrad(dh1, w0, C3, x1.shape, 0 if x2 is None else x2.shape[-1])
 
     def _up_bwd(self, dy):
         _, name, x, wt = self.tape.pop()
-        self.grads[name + ".weight"], self.grads[name + ".bias"] = ops.convT_wgrad(
-            x, dy, (2, 2), self.P[name + ".weight"].shape)
+        self.grads[name + ".weight"], self.grads[name + ".bias"] = self._wg(
+            ops.convT_wgrad, x, dy, (2, 2), self.P[name + ".weight"].shape)
         return ops.convT_dgrad(dy, wt, (2, 2), x.shape)
 
     def _pad_bwd(self, d):
@@ -145,9 +160,14 @@ class _Run2d:
         return ops.maxpool2d_bwd(dy, idx, shape, skip)
 
     def backward(self, dlogits, need_dx):
+        from .unet3d import _side_stream, _side_events
+        self.side = _side_stream(dlogits.device)
+        self._keep, self._nev = [], 0
+        if self.side is not None:
+            self._events = _side_events(dlogits.device)
         _, c9, wp = self.tape.pop()
-        self.grads["conv10.weight"], self.grads["conv10.bias"] = ops.conv_wgrad(
-            c9, None, dlogits, C1, self.P["conv10.weight"].shape)
+        self.grads["conv10.weight"], self.grads["conv10.bias"] = self._wg(
+            ops.conv_wgrad, c9, None, dlogits, C1, self.P["conv10.weight"].shape)
         d = ops.conv_dgrad(dlogits, wp, C1, c9.shape)[0]
         a, b = self._dc_bwd(d)                         # conv9
         if self.drive:
@@ -169,6 +189,9 @@ class _Run2d:
         d, _ = self._dc_bwd(d)                         # conv2
         d = self._pool_bwd(d, dc1)
         d, _ = self._dc_bwd(d, need_dx)                # conv1
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self._keep = []                                # freed behind the join, on the stream that allocated them
         return d
 
 

@@ -151,17 +151,16 @@ def test_gradients_are_views_of_one_flat_buffer():
 
 
 def test_backward_reproducibility_one_and_two_streams(monkeypatch):
-    """One stream (DEVIS_WGRAD_STREAM=0): the same batch gives the same gradient bits every time.  Two streams
-    (default: weight gradients on a side stream): a few bf16 roundings of the activation gradients move from run to
-    run, which shows in gradients that are rounding noise themselves (conv biases in front of a
-    BatchNorm); over the whole flat gradient the two modes must agree to 1e-3."""
+    """The same batch gives the same gradient bits every time, with the weight gradients on the side stream
+    (default) and with everything on one stream (DEVIS_WGRAD_STREAM=0), and the two modes give the same bits.
+    (Packed fp32 VALU instructions broke this - DESIGN.md 6 - and are compiled out.)"""
     from devis_amd import TMSU
     from tests.util import brats_args
     torch.manual_seed(0)
     m = TMSU(brats_args(compute_dtype=torch.bfloat16)).train()
     g = torch.Generator().manual_seed(2)
-    x = torch.randn((1, 4, 64, 64, 64), generator=g).cuda()
-    y = torch.randint(0, 4, (1, 64, 64, 64), generator=g).cuda()
+    x = torch.randn((2, 4, 64, 64, 64), generator=g).cuda()
+    y = torch.randint(0, 4, (2, 64, 64, 64), generator=g).cuda()
 
     def grads():
         _, loss = m(x, y, 25, 'train', 'BraTS')
@@ -169,12 +168,11 @@ def test_backward_reproducibility_one_and_two_streams(monkeypatch):
             p.grad = None
         loss.backward()
         torch.cuda.synchronize()
-        return torch.cat([p.grad.flatten() for p in m.parameters()]).double()
+        return torch.cat([p.grad.flatten() for p in m.parameters()])
 
     monkeypatch.setenv("DEVIS_WGRAD_STREAM", "0")
     ref = grads()
-    assert torch.equal(grads(), ref) and torch.equal(grads(), ref)
+    assert torch.equal(grads(), ref)
     monkeypatch.setenv("DEVIS_WGRAD_STREAM", "1")
-    for _ in range(4):
-        cur = grads()
-        assert float((cur - ref).norm() / ref.norm()) < 1e-3
+    for _ in range(6):
+        assert torch.equal(grads(), ref)
