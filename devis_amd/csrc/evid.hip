@@ -58,8 +58,8 @@ __device__ __forceinline__ void psi_lgamma_f(float x, float& psi, float& lg) {
   psi = (lx - 0.5f * xi - pser) - (small ? num * rcp_f(P) : 0.f);
   lg = ((X - 0.5f) * lx - X + 0.91893853320467f + lser) - (small ? log_f(P) : 0.f);
 }
-// two arguments at once: the polynomial parts become packed fp32 instructions (v_pk_mul/fma_f32: two lanes' worth
-// of FMAs per issue on gfx950); the kernels below are VALU-bound, not HBM-bound, so this is where their time is
+// two arguments at once (written on 2-vectors; the build compiles packed fp32 instructions out, see build.sh, so
+// these become pairs of scalar FMAs with the shared control flow of one call)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void psi_lgamma_f2(f32x2 x, f32x2& psi, f32x2& lg) {
   const bool s0 = x.x < 6.f, s1 = x.y < 6.f;
