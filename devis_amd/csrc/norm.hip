@@ -254,13 +254,42 @@ __global__ void k_norm_bwd_finalize(const double* __restrict__ mom, int64_t N, i
 // path of every norm layer).  reduce_chunks() adds the chunk partials of `nout` consecutive doubles starting at
 // partial[n][.][c0][0], for nn samples from n0, into sm[(n - n0) * nout + o].
 __device__ __forceinline__ void reduce_chunks(const double* __restrict__ partial, int64_t chunks, int64_t C, int64_t n0,
-                                              int nn, int64_t c0, int nout, double* __restrict__ sm) {
+                                              int nn, int64_t c0, int nout, double* __restrict__ sm, int fast) {
+  const int64_t st = C * 2;
+  if (fast) {
+    // nout is a power of two <= 64 and the block has 1024 threads: lanes run along the nout contiguous doubles
+    // of a chunk row first (whole 32-byte sectors per wave load), then along chunks; eight independent loads in
+    // flight per lane; equal-j lanes combine in a fixed xor tree, the 16 waves through LDS in wave order.
+    const int t = threadIdx.x, nw = (int)(blockDim.x >> 6), lane = t & 63, wave = t >> 6;
+    const int j = t & (nout - 1), r = t / nout, RT = (int)blockDim.x / nout;
+    double* wsum = sm + nn * nout;                     // [nn][nw][nout]
+    for (int n = 0; n < nn; ++n) {
+      const double* p = partial + ((n0 + n) * chunks * C + c0) * 2 + j;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+      int64_t k = r;
+      for (; k + 7 * RT < chunks; k += 8 * RT) {
+        a0 += p[k * st]; a1 += p[(k + RT) * st]; a2 += p[(k + 2 * RT) * st]; a3 += p[(k + 3 * RT) * st];
+        a4 += p[(k + 4 * RT) * st]; a5 += p[(k + 5 * RT) * st]; a6 += p[(k + 6 * RT) * st]; a7 += p[(k + 7 * RT) * st];
+      }
+      for (; k < chunks; k += RT) a0 += p[k * st];
+      double a = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+      for (int w = nout; w < 64; w <<= 1) a += __shfl_xor(a, w, 64);
+      if (lane < nout) wsum[(n * nw + wave) * nout + lane] = a;
+    }
+    __syncthreads();
+    for (int o = t; o < nn * nout; o += (int)blockDim.x) {
+      const double* q = wsum + (o / nout) * nw * nout + o % nout;
+      double s = 0.0;
+      for (int w = 0; w < nw; ++w) s += q[w * nout];
+      sm[o] = s;
+    }
+    return;
+  }
   // one wave per output, four independent loads in flight per lane, fixed xor tree: deterministic
   const int sub = threadIdx.x & 63;
   for (int o = threadIdx.x >> 6; o < nn * nout; o += (int)(blockDim.x >> 6)) {
     const int64_t n = n0 + o / nout;
     const double* p = partial + (n * chunks * C + c0) * 2 + o % nout;
-    const int64_t st = C * 2;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int64_t k = sub;
     for (; k + 192 < chunks; k += 256) {
@@ -279,10 +308,10 @@ __global__ void __launch_bounds__(1024)
 k_gn_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                 float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
-                float* __restrict__ rstd) {
+                float* __restrict__ rstd, int fast) {
   extern __shared__ double sm[];
   const int64_t i = blockIdx.x, n = i / G, g = i % G, cpg = C / G;
-  reduce_chunks(partial, chunks, C, n, 1, g * cpg, (int)(cpg * 2), sm);
+  reduce_chunks(partial, chunks, C, n, 1, g * cpg, (int)(cpg * 2), sm, fast);
   __syncthreads();
   double s = 0.0, ss = 0.0;
   for (int64_t c = 0; c < cpg; ++c) { s += sm[c * 2]; ss += sm[c * 2 + 1]; }
@@ -305,10 +334,10 @@ k_bn_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, i
                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                 float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ tracked,
                 float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
-                float* __restrict__ rstd) {
+                float* __restrict__ rstd, int fast) {
   extern __shared__ double sm[];
   const int64_t c = blockIdx.x;
-  reduce_chunks(partial, chunks, C, 0, (int)N, c, 2, sm);
+  reduce_chunks(partial, chunks, C, 0, (int)N, c, 2, sm, fast);
   __syncthreads();
   double s = 0.0, ss = 0.0;
   for (int64_t n = 0; n < N; ++n) { s += sm[n * 2]; ss += sm[n * 2 + 1]; }
@@ -337,11 +366,11 @@ __global__ void __launch_bounds__(1024)
 k_norm_bwd_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
                       int bn, const float* __restrict__ gamma, const float* __restrict__ mean,
                       const float* __restrict__ rstd, float* __restrict__ cA, float* __restrict__ cB,
-                      float* __restrict__ cC, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                      float* __restrict__ cC, float* __restrict__ dgamma, float* __restrict__ dbeta, int fast) {
   extern __shared__ double sm[];
   if (bn) {
     const int64_t c = blockIdx.x;
-    reduce_chunks(partial, chunks, C, 0, (int)N, c, 2, sm);
+    reduce_chunks(partial, chunks, C, 0, (int)N, c, 2, sm, fast);
     __syncthreads();
     double m0 = 0.0, m1 = 0.0;
     for (int64_t n = 0; n < N; ++n) { m0 += sm[n * 2]; m1 += sm[n * 2 + 1]; }
@@ -357,7 +386,7 @@ k_norm_bwd_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_
     if (threadIdx.x == 0) { dgamma[c] = (float)(r * (m1 - mu * m0)); dbeta[c] = (float)m0; }
   } else {
     const int64_t g = blockIdx.x, cpg = C / G;
-    reduce_chunks(partial, chunks, C, 0, (int)N, g * cpg, (int)(cpg * 2), sm);
+    reduce_chunks(partial, chunks, C, 0, (int)N, g * cpg, (int)(cpg * 2), sm, fast);
     __syncthreads();
     const double M = (double)cpg * (double)V;
     for (int64_t cl = threadIdx.x; cl < cpg; cl += blockDim.x) {
@@ -712,14 +741,22 @@ int devis_norm_bwd_moments_partials(const void* dy, const void* x, const float* 
 #define DEVIS_FINALIZE_SMEM_MAX (48 * 1024)
 // one wave per output, at most 16 waves
 static inline unsigned fin_threads(int64_t nout) { return (unsigned)(64 * (nout < 1 ? 1 : (nout > 16 ? 16 : nout))); }
+// The sector-coalesced reduction (reduce_chunks, fast): nout a power of two <= 64, 17x the LDS, 1024 threads.
+struct FinPlan { int fast; unsigned threads; size_t smem; };
+static inline FinPlan fin_plan(int64_t nn, int64_t nout) {
+  static const bool off = getenv("DEVIS_NO_FAST_FINALIZE") != nullptr;
+  const size_t slow = (size_t)(nn * nout) * sizeof(double), quick = slow * 17;
+  if (!off && nout >= 1 && nout <= 64 && (nout & (nout - 1)) == 0 && quick <= DEVIS_FINALIZE_SMEM_MAX) return {1, 1024u, quick};
+  return {0, fin_threads(nn * nout), slow};
+}
 
 int devis_gn_finalize_partials(const double* partials, int64_t chunks, int64_t N, int64_t V, int64_t C, int64_t G,
                                const float* gamma, const float* beta, float eps, float* scale, float* shift,
                                float* mean, float* rstd, void* stream) {
   if (!partials || chunks <= 0 || !gamma || !beta || !scale || !shift || !mean || !rstd || N <= 0 || V <= 0 || G <= 0 || C % G) return DEVIS_ERR_BAD_ARG;
-  const size_t smem = (size_t)(C / G) * 2 * sizeof(double);
-  if (smem > DEVIS_FINALIZE_SMEM_MAX || N * G > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_gn_finalize_p, dim3((unsigned)(N * G)), dim3(fin_threads((C / G) * 2)), smem, (hipStream_t)stream, partials, chunks, N, V, C, G, gamma, beta, eps, scale, shift, mean, rstd);
+  const FinPlan fp = fin_plan(1, (C / G) * 2);
+  if (fp.smem > DEVIS_FINALIZE_SMEM_MAX || N * G > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gn_finalize_p, dim3((unsigned)(N * G)), dim3(fp.threads), fp.smem, (hipStream_t)stream, partials, chunks, N, V, C, G, gamma, beta, eps, scale, shift, mean, rstd, fp.fast);
   return launch_status();
 }
 
@@ -729,9 +766,9 @@ int devis_bn_finalize_partials(const double* partials, int64_t chunks, int64_t N
                                float* rstd, void* stream) {
   if (!partials || chunks <= 0 || !gamma || !beta || !scale || !shift || !mean || !rstd || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
   if ((rmean == nullptr) != (rvar == nullptr)) return DEVIS_ERR_BAD_ARG;
-  const size_t smem = (size_t)N * 2 * sizeof(double);
-  if (smem > DEVIS_FINALIZE_SMEM_MAX || C > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_bn_finalize_p, dim3((unsigned)C), dim3(fin_threads(N * 2)), smem, (hipStream_t)stream, partials, chunks, N, V, C, gamma, beta, eps, momentum, rmean, rvar, num_batches_tracked, scale, shift, mean, rstd);
+  const FinPlan fp = fin_plan(N, 2);
+  if (fp.smem > DEVIS_FINALIZE_SMEM_MAX || C > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_bn_finalize_p, dim3((unsigned)C), dim3(fp.threads), fp.smem, (hipStream_t)stream, partials, chunks, N, V, C, gamma, beta, eps, momentum, rmean, rvar, num_batches_tracked, scale, shift, mean, rstd, fp.fast);
   return launch_status();
 }
 
@@ -740,9 +777,9 @@ int devis_norm_bwd_finalize_partials(const double* partials, int64_t chunks, int
                                      float* cA, float* cB, float* cC, float* dgamma, float* dbeta, void* stream) {
   if (!partials || chunks <= 0 || !gamma || !mean || !rstd || !cA || !cB || !cC || !dgamma || !dbeta || N <= 0 || V <= 0 || C <= 0) return DEVIS_ERR_BAD_ARG;
   if (!bn && (G <= 0 || C % G)) return DEVIS_ERR_BAD_ARG;
-  const size_t smem = (size_t)N * (bn ? 1 : C / G) * 2 * sizeof(double);
-  if (smem > DEVIS_FINALIZE_SMEM_MAX) return DEVIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_norm_bwd_finalize_p, dim3((unsigned)(bn ? C : G)), dim3(fin_threads(N * (bn ? 1 : C / G) * 2)), smem, (hipStream_t)stream, partials, chunks, N, V, C, G, bn, gamma, mean, rstd, cA, cB, cC, dgamma, dbeta);
+  const FinPlan fp = fin_plan(N, (bn ? 1 : C / G) * 2);
+  if (fp.smem > DEVIS_FINALIZE_SMEM_MAX) return DEVIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_norm_bwd_finalize_p, dim3((unsigned)(bn ? C : G)), dim3(fp.threads), fp.smem, (hipStream_t)stream, partials, chunks, N, V, C, G, bn, gamma, mean, rstd, cA, cB, cC, dgamma, dbeta, fp.fast);
   return launch_status();
 }
 
