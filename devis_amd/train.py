@@ -221,3 +221,79 @@ def val(args, model, current_epoch, best_dice, valid_loader, save=True):
             os.makedirs(args.save_dir, exist_ok=True)
             torch.save({'epoch': current_epoch, 'state_dict': model.state_dict()}, os.path.join(args.save_dir, name))
     return meter.avg, best_dice
+
+
+_REGIONS = {'BraTS': ('WT', 'TC', 'ET'), 'LiTS': ('liver', 'tumor')}
+UEO_THRESHOLDS = (0.05, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95)      # trainUMIS.py:521
+
+
+def _region_scores(conf, dataset, num_classes):
+    """dice and IoU lists as predict.py:386-416 / 296-300 form them, from the K x K confusion counts."""
+    from .predict import dice_score, mIOU
+    if dataset == 'BraTS':
+        regions = [range(1, num_classes), (1, 3), (3,)]
+    elif dataset == 'LiTS':
+        regions = [(1, 2), (2,)]
+    else:
+        regions = [(k,) for k in range(1, num_classes)]
+    return [dice_score(conf, r) for r in regions], [mIOU(conf, r) for r in regions]
+
+
+def test(args, model, test_loader, log=print):
+    """The tensor part of trainUMIS.py:333-1000 (mode 'test'): load `<model>_<dataset>_<folder>[_DUloss]_epoch_<n>.pth`
+    (:393-409), then for every (input, noised_input, target): evidence of both inputs, argmax(alpha/S), u = K/S,
+    normalised entropy, 1-u / exp(-u) means, region dice / IoU and the per-threshold uncertainty confusion counts -
+    all reduced on the GPU (predict_volume + evaluate_volume), one small host copy per volume.  Returns the averages
+    the reference logs at the end.  Not computed: Hausdorff / ASSD (medpy), ECE (`ece_binary`) and the UEO score
+    (`UncertaintyAndCorrectionEvalNumpy`, predict.py:20,53: its module is not in the reference) - the threshold
+    counts they are formed from are returned instead (`ucount`)."""
+    import time
+    from .predict import evaluate_volume
+    tag = '_DUloss' if args.Uncertainty_Loss else ''
+    name = '%s_%s_%s%s_epoch_%s.pth' % (args.model_name, args.dataset, args.folder, tag, args.test_epoch)
+    load_file = os.path.join(args.save_dir, name)
+    if os.path.exists(load_file):
+        checkpoint = torch.load(load_file, map_location='cpu', weights_only=True)
+        model.load_state_dict(checkpoint['state_dict'])
+        args.start_epoch = checkpoint['epoch']
+        log('Successfully load checkpoint %s' % load_file)
+    else:
+        log('There is no resume file to load!')
+    k = {'BraTS': 4, 'LiTS': 3, 'TOAR': 7, 'HC': 9}.get(args.dataset, 2)         # trainUMIS.py:419-428
+    model.eval()
+    args.mode = 'test'
+    keys = ('dice', 'iou', 'mean_u', 'mean_conf', 'mean_confe', 'mne')
+    tot = {c: {q: 0.0 for q in keys} for c in ('clean', 'noise')}
+    ucount = {'clean': 0, 'noise': 0}
+    runtimes, n = [], 0
+    for data in test_loader:
+        x, noised_x, target = data[0].cuda(), data[1].cuda(), data[-1].cuda()
+        if args.dataset == 'BraTS':
+            target = target[..., :155]
+        torch.cuda.synchronize()
+        t0 = time.time()
+        outs = {'clean': predict_volume(model, x, args.dataset, UEO_THRESHOLDS),
+                'noise': predict_volume(model, noised_x, args.dataset, UEO_THRESHOLDS)}
+        torch.cuda.synchronize()
+        runtimes.append(time.time() - t0)
+        n += 1
+        for c, out in outs.items():
+            r = evaluate_volume(out, target, k, len(UEO_THRESHOLDS))
+            dice, iou = _region_scores(r['conf'], args.dataset, k)
+            t = tot[c]
+            t['dice'] = t['dice'] + np.asarray(dice)
+            t['iou'] = t['iou'] + np.asarray(iou)
+            for q in ('mean_u', 'mean_conf', 'mean_confe'):
+                t[q] += float(r[q])
+            t['mne'] += float(out['mne'].double().mean().item())
+            ucount[c] = ucount[c] + r['ucount']
+            log('%s subject %d: dice %s  U %.6f  conf %.6f  confe %.6f' %
+                (c, n, np.round(dice, 4).tolist(), r['mean_u'], r['mean_conf'], r['mean_confe']))
+    res = {}
+    for c in tot:
+        for q in keys:
+            res[c + '_' + q] = tot[c][q] / max(n, 1)
+        res[c + '_ucount'] = ucount[c]
+    res['regions'] = _REGIONS.get(args.dataset)
+    res['runtime'] = float(np.mean(runtimes)) if runtimes else 0.0
+    return res

@@ -96,3 +96,42 @@ def test_sliding_window_infer_equals_stitch_then_head():
             assert torch.equal(both.to(ref[k].dtype), ref[k]), (str(dtype), k)
         # supports are disjoint
         assert int(((halves[0]["u"] != 0) & (halves[1]["u"] != 0)).sum()) == 0
+
+
+def test_test_mode_driver_loads_checkpoint_and_reports_device_side_metrics(tmp_path):
+    """train.test() (trainUMIS.py:333-...): the checkpoint val() wrote is the one it loads (reference file name),
+    and its dice / IoU / uncertainty means equal the oracle's numpy restatement on host copies of the same maps."""
+    from oracle import devis_oracle as O
+    from devis_amd import TMSU, train as T, predict as P
+    from tests.util import brats_args
+    torch.manual_seed(0)
+    args = brats_args(compute_dtype=torch.float32, save_dir=str(tmp_path), folder='folder0', test_epoch=3, mode='test')
+    m = TMSU(args)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, 4, 240, 240, 160), generator=g)
+    noised = x + 0.5 * torch.randn((1, 4, 240, 240, 160), generator=g)
+    target = torch.randint(0, 4, (1, 240, 240, 160), generator=g)
+    # val() with best_dice = -1 always checkpoints under the reference's name
+    _, best = T.val(args, m, 3, -1.0, [(x, target)])
+    assert (tmp_path / "U_BraTS_folder0_epoch_3.pth").exists()
+    want = T.predict_volume(m, x.cuda(), 'BraTS', T.UEO_THRESHOLDS)
+    want = {k: v.clone() for k, v in want.items() if torch.is_tensor(v)}
+    with torch.no_grad():                                   # spoil the weights: test() must restore them
+        for p in m.parameters():
+            p.mul_(0.5)
+    lines = []
+    res = T.test(args, m, [(x, noised, target)], log=lines.append)
+    assert args.start_epoch == 3 and lines[0].startswith('Successfully load checkpoint')
+    got = T.predict_volume(m, x.cuda(), 'BraTS', T.UEO_THRESHOLDS)
+    assert torch.equal(got["pred"], want["pred"]) and torch.equal(got["u"], want["u"])
+    t = target[0, ..., :155].numpy()
+    conf, ucount, sums = O.eval_counts(want["pred"].cpu().numpy().reshape(t.shape), t,
+                                       want["u"].cpu().numpy().reshape(t.shape), T.UEO_THRESHOLDS, 4)
+    assert np.array_equal(res["clean_ucount"], ucount)
+    assert np.allclose(res["clean_dice"], P.softmax_output_dice(conf), atol=1e-12)
+    assert abs(res["clean_dice"][0] - 2.0 * ((want["pred"].cpu().numpy().reshape(t.shape) > 0) & (t > 0)).sum()
+               / ((want["pred"].cpu().numpy() > 0).sum() + (t > 0).sum())) < 1e-9
+    assert abs(res["clean_mean_u"] - sums[0] / t.size) < 1e-6
+    assert abs(res["clean_mne"] - float(want["mne"].double().mean())) < 1e-9
+    assert res["regions"] == ('WT', 'TC', 'ET') and res["runtime"] > 0
+    assert abs(res["noise_mean_u"] - res["clean_mean_u"]) > 0          # the noised input went through too
