@@ -63,3 +63,45 @@ def test_isic_plumbing_shape():
     ev, loss = m(x, y, 25, 'train', 'ISIC')
     loss.backward()
     assert ev.shape == (1, 2, 224, 300) and torch.isfinite(loss)
+
+
+def test_full_size_config2_train_step_vs_oracle_live():
+    """BASELINE configs[1] at its full size (Unet2D(1,2), batch 16 of 1x256x256, epoch 25): loss, logits and every
+    parameter's gradient norm of one train step against the CPU oracle run live on the same seeded tensors.
+    fp32: loss 1e-5 rel, logits 5e-5 rel-max, gradient norms GRAD_L2_TOL; bf16: loss 1e-3 abs, logits 3e-2,
+    gradient norms 8 %."""
+    import numpy as np
+    from oracle import devis_oracle as O
+    from devis_amd import Unet2D
+    from devis_amd.criterions import evidential_head_loss
+    g = torch.Generator().manual_seed(2100)
+    x = torch.randn((16, 1, 256, 256), generator=g)
+    y = (torch.rand((16, 1, 256, 256), generator=g) > 0.5).long()
+    torch.manual_seed(4)
+    sd = {k: v.detach().clone() for k, v in Unet2D(1, 2, compute_dtype=torch.float32).state_dict().items()}
+    names = [k for k in sd if sd[k].is_floating_point() and k.split('.')[-1] in ("weight", "bias")]
+    for k in names:
+        sd[k].requires_grad_(True)
+    logits_ref = []
+    def backbone(t):
+        logits_ref.append(O.unet2d_forward(sd, t, True))
+        return logits_ref[0]
+    _, loss_ref = O.tmsu_forward(backbone, x, y, 25, 'train', 'HC', 2, 50, 100)
+    loss_ref.backward()
+    ref = np.array([sd[k].grad.double().norm().item() for k in sorted(names)])
+    lref = logits_ref[0].detach()
+    loss_ref = float(loss_ref.detach())
+    for dtype, ltol, ztol, gtol, gatol in ((torch.float32, 1e-5 * abs(loss_ref) + 1e-6, 5e-5, GRAD_L2_TOL, 1e-6),
+                                           (torch.bfloat16, 1e-3, 3e-2, 0.08, 1e-3)):
+        torch.manual_seed(4)
+        net = Unet2D(1, 2, compute_dtype=dtype).cuda().train()
+        logits_cl = net.forward_channels_last(x.cuda())
+        _, loss = evidential_head_loss(logits_cl, y.cuda(), 25, 50, channels_last=True, want_evidence=False)
+        loss.backward()
+        assert abs(loss.item() - loss_ref) < ltol, (dtype, loss.item(), loss_ref)
+        assert rel_err(logits_cl.detach().permute(0, 3, 1, 2).float(), lref) < ztol, dtype
+        params = dict(net.named_parameters())
+        assert sorted(params) == sorted(names)
+        norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
+        assert np.all(np.abs(norms - ref) <= gtol * ref + gatol * ref.max()), \
+            (dtype, np.max(np.abs(norms - ref) / (ref + 1e-30)))

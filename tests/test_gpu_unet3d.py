@@ -176,3 +176,36 @@ def test_backward_reproducibility_one_and_two_streams(monkeypatch):
     monkeypatch.setenv("DEVIS_WGRAD_STREAM", "1")
     for _ in range(6):
         assert torch.equal(grads(), ref)
+
+
+def test_full_size_config3_train_step_vs_oracle_live():
+    """BASELINE configs[2] at its full size (B=2, 4x128^3, K=4, epoch 25): loss, evidence and every parameter's
+    gradient norm of ONE train step against the CPU oracle run live on the same seeded tensors (a few seconds on
+    the box's host cores).  fp32: loss 1e-5 rel, evidence 5e-5 rel-max, gradient norms GRAD_L2_TOL;
+    bf16: loss 1e-3 abs, evidence 2e-2, gradient norms 8 % (the bars of the small golden cases)."""
+    from oracle import devis_oracle as O
+    shape = (2, 4, 128, 128, 128)
+    x, y = _inputs(11, shape)
+    m = _make(11, torch.float32)
+    sd = {k: v.detach().cpu().clone() for k, v in m.backbone.state_dict().items()}
+    names = [k for k, _ in m.backbone.named_parameters()]
+    for k in names:
+        sd[k].requires_grad_(True)
+    ev_ref, loss_ref = O.tmsu_forward(lambda t: O.unet3d_forward(sd, t, True), x, y, 25, 'train', 'BraTS', 4, 50, 100)
+    loss_ref.backward()
+    ref = np.array([sd[k].grad.double().norm().item() for k in sorted(names)])
+    ev_ref = ev_ref.detach()[..., ::4, ::4, ::4].clone()
+    loss_ref = float(loss_ref.detach())
+    for dtype, ltol, etol, gtol, gatol in ((torch.float32, 1e-5 * abs(loss_ref) + 1e-6, 5e-5, GRAD_L2_TOL, 1e-6),
+                                           (torch.bfloat16, 1e-3, 2e-2, 0.08, 1e-3)):
+        m = _make(11, dtype)
+        ev, loss = m(x.cuda(), y.cuda(), 25, 'train', 'BraTS')
+        loss.backward()
+        assert abs(loss.item() - loss_ref) < ltol, (dtype, loss.item(), loss_ref)
+        assert rel_err(ev.detach()[..., ::4, ::4, ::4], ev_ref) < etol, dtype
+        params = dict(m.backbone.named_parameters())
+        norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
+        assert np.all(np.abs(norms - ref) <= gtol * ref + gatol * ref.max()), \
+            (dtype, np.max(np.abs(norms - ref) / (ref + 1e-30)))
+        del m, ev, loss, params
+        torch.cuda.empty_cache()
