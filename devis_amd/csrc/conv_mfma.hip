@@ -366,7 +366,11 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
     if (ci == 64 && co == 64) return CONV3(64, 64, 4, 4, 16, 1);
     if (ci == 128 && co == 128) return CONV3(128, 32, 2, 4, 16, 1);
   } else if (st_ == 2) {
+    // 32 -> 64: the (2,4,16) tile re-reads less halo than (2,2,16): 36 vs 41 us at 64^3 (tools/time_s2_fwd.py);
+    // for 16 -> 32 the larger (4,4,16) tile was measured at 145 vs 86 us (one block per CU) and is not built
+    static const bool small32 = getenv("DEVIS_S2_SMALL_TILE") != nullptr;
     if (ci == 16 && co == 32) return CONV3(16, 32, 2, 4, 16, 2, 1);
+    if (ci == 32 && co == 64 && !small32) return CONV3(32, 64, 2, 4, 16, 2, 1);
     if (ci == 32 && co == 64) return CONV3(32, 64, 2, 2, 16, 2, 1);
     if (ci == 64 && co == 128) return CONV3(64, 64, 2, 2, 16, 2, 1);
   }
