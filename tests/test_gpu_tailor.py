@@ -135,3 +135,39 @@ def test_test_mode_driver_loads_checkpoint_and_reports_device_side_metrics(tmp_p
     assert abs(res["clean_mne"] - float(want["mne"].double().mean())) < 1e-9
     assert res["regions"] == ('WT', 'TC', 'ET') and res["runtime"] > 0
     assert abs(res["noise_mean_u"] - res["clean_mean_u"]) > 0          # the noised input went through too
+
+
+def test_full_volume_config5_inference_vs_oracle_live():
+    """BASELINE configs[4] at full size: one 4x240x240x160 volume through predict_volume (8 patches, backbone in
+    eval mode + fused head, fp32) against the oracle's tailor_and_concat + infer_head run live on the host cores.
+    evidence 5e-5 rel-max; u and mne 1e-5 abs; the argmax mask and the eleven u-threshold masks are integers and
+    must agree wherever the oracle's own decision margin exceeds the evidence tolerance (every voxel that
+    disagrees must be such a near-tie, and there must be next to none)."""
+    from oracle import devis_oracle as O
+    from devis_amd import TMSU, train as T
+    from tests.util import brats_args, rel_err
+    torch.manual_seed(0)
+    m = TMSU(brats_args(compute_dtype=torch.float32)).eval()
+    sd = {k: v.detach().cpu().clone() for k, v in m.backbone.state_dict().items()}
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn((1, 4, 240, 240, 160), generator=g)
+    thr = O.UNCERTAINTY_THRESHOLDS
+    out = T.predict_volume(m, x.cuda(), 'BraTS', thr)
+    with torch.no_grad():
+        ev = O.tmsu_forward(lambda t: O.unet3d_forward(sd, t, False), x, None, 0, 'test', 'BraTS', 4, 50, 100)
+        pred, u, prob, mne = O.infer_head(ev, 4)
+    assert out["evidence"].shape == ev.shape == (1, 4, 240, 240, 155)
+    tol = 5e-5 * float(ev.abs().max())
+    assert (out["evidence"].cpu() - ev).abs().max() < tol
+    assert (out["u"].cpu().reshape(u.shape) - u).abs().max() < 1e-5
+    assert (out["mne"].cpu().reshape(mne.shape) - mne).abs().max() < 1e-5
+    ours = out["pred"].cpu().reshape(pred.shape).long()
+    diff = ours != pred
+    top2 = prob.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])
+    assert int(diff.sum()) <= 1e-5 * diff.numel() and bool((margin[diff] < 1e-4).all()), int(diff.sum())
+    um = out["umask"].cpu().reshape(u.shape).int()
+    for j, t in enumerate(thr):
+        want = u > np.float32(t)
+        d = ((um >> j) & 1).bool() != want
+        assert bool(((u[d] - np.float32(t)).abs() < 1e-5).all()) and int(d.sum()) <= 1e-5 * d.numel(), (t, int(d.sum()))
