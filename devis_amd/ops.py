@@ -85,13 +85,18 @@ def _spatial(x: Tensor) -> Tuple[int, int, int]:
 
 
 _ws = {}
+_ws_retired = []
 
 
 def workspace(nbytes: int, device: torch.device, slot: str = "ws") -> Tensor:
-    """Per-device scratch that only ever grows (the library itself never allocates)."""
-    key = (device.index, slot)
+    """Scratch that only ever grows (the library itself never allocates), one buffer per (device, slot, STREAM the
+    calls launch on): kernels of different streams run concurrently and must not share it.  A buffer that is
+    outgrown is retired, not freed - a captured HIP graph may still hold its address."""
+    key = (device.index, slot, _stream())
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
+        if t is not None:
+            _ws_retired.append(t)
         t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws[key] = t
     return t

@@ -55,8 +55,103 @@ def _default_head(backbone, thresholds, want_evidence, want_mne):
     return run
 
 
+class GraphedPatchHead:
+    """backbone + fused inference head of ONE patch on ONE stream, captured in a HIP graph and replayed per patch.
+    Same kernels, same order: the maps are bit-identical to the eager run.  Captured inside
+    `backbone.frozen_weights()`, so the graph holds no weight packing: the caller re-packs once per volume and the
+    replays read that packing (parameter updates between volumes are seen).  `stale()` tells when to rebuild
+    (mode flip, another patch shape, parameters / buffers / packing re-allocated).  The returned maps are the
+    graph's own output buffers: consume them on the same stream before the next call."""
+
+    def __init__(self, backbone, stream, thresholds, want_evidence, want_mne, shape, dtype, dev):
+        if backbone.training:
+            raise RuntimeError("GraphedPatchHead captures the eval-mode forward: call backbone.eval() first")
+        self.backbone, self.stream = backbone, stream
+        self._run = _default_head(backbone, thresholds, want_evidence, want_mne)
+        self._ident = self._identity()
+        cur = torch.cuda.current_stream(dev)
+        stream.wait_stream(cur)
+        with torch.cuda.stream(stream), torch.no_grad():
+            self.static_in = torch.zeros(tuple(shape), dtype=dtype, device=dev)
+            for _ in range(2):                                  # warm-up outside the capture
+                self._run(self.static_in)
+        stream.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=stream):
+            self.static_out = self._run(self.static_in)
+        cur.wait_stream(stream)
+
+    def _identity(self):
+        b = self.backbone
+        return (id(b._packer),) + tuple(t.data_ptr() for t in list(b.parameters()) + list(b.buffers()))
+
+    def stale_for(self, shape, dtype, device) -> bool:
+        return (self.backbone.training or tuple(shape) != tuple(self.static_in.shape)
+                or dtype != self.static_in.dtype or device != self.static_in.device
+                or self._identity() != self._ident)
+
+    def __call__(self, patch):
+        """on self.stream (the caller has made it current)"""
+        self.static_in.copy_(patch)
+        self.graph.replay()
+        return self.static_out
+
+
+_PATCH_STREAMS = {}
+
+
+def _patch_streams(device, n):
+    """n cached streams of `device` for the patch rotation."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    have = _PATCH_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
+def _graphed_volume(x, backbone, thresholds, want_evidence, want_mne, groups, streams, out, vol):
+    """The patch loop of sliding_window_infer with each patch (group) replayed from a HIP graph, rotated over
+    `streams` streams.  One GraphedPatchHead per stream, cached on the backbone."""
+    dev = x.device
+    cur = torch.cuda.current_stream(dev)
+    ns = max(1, min(int(streams), len(groups)))
+    sts = _patch_streams(dev, ns)
+    cache = backbone.__dict__.setdefault("_devis_patch_graphs", {})
+    with backbone.frozen_weights():
+        ready = torch.cuda.Event()
+        ready.record(cur)                                   # x and the packed weights exist
+        for gi, group_ids in enumerate(groups):
+            st = sts[gi % ns]
+            shape = (len(group_ids),) + tuple(crop(x, group_ids[0]).shape[1:])
+            key = (gi % ns, tuple(thresholds), bool(want_evidence), bool(want_mne), shape, x.dtype)
+            head = cache.get(key)
+            if head is None or head.stale_for(shape, x.dtype, x.device):
+                cache[key] = head = GraphedPatchHead(backbone, st, thresholds, want_evidence, want_mne, shape, x.dtype, dev)
+            if not out:                                     # volume maps: allocated and zeroed on the caller's stream
+                for k, t in head.static_out.items():
+                    if t is not None:
+                        lead = (1,) + tuple(t.shape[1:t.dim() - 3])
+                        out[k] = torch.zeros(lead + vol, dtype=t.dtype, device=dev)
+                ready = torch.cuda.Event()
+                ready.record(cur)
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                # the crops are made on the stream that consumes them (x is complete: `ready`)
+                patches = [crop(x, i) for i in group_ids]
+                maps = head(patches[0] if len(patches) == 1 else torch.cat(patches, dim=0))
+                for j, i in enumerate(group_ids):
+                    dst, src = patch_regions(i)
+                    for k, t in maps.items():
+                        if t is not None:
+                            out[k][(Ellipsis,) + dst] = t[j:j + 1][(Ellipsis,) + src]
+        for st in sts:
+            cur.wait_stream(st)
+    return out
+
+
 def sliding_window_infer(x, backbone, thresholds=(), rank: int = 0, world: int = 1, group=None,
-                         want_evidence: bool = False, want_mne: bool = True, patch_fn=None, patch_batch: int = 1):
+                         want_evidence: bool = False, want_mne: bool = True, patch_fn=None, patch_batch: int = 1,
+                         graph_streams: int = 0):
     """Sharded form of the BraTS val/test forward (predict.py:159-191 + trainUMIS.py:286-290,446-461,521):
     patch i runs on rank i % world, each rank applies the fused inference head to its own
     patches and writes their kept sub-regions into zero-initialised volume maps; the regions are disjoint, so
@@ -69,6 +164,9 @@ def sliding_window_infer(x, backbone, thresholds=(), rank: int = 0, world: int =
     BatchNorm uses its running statistics), so fp32 maps are the same bits as the reference's one-by-one order;
     in bf16 the kernels' tile shapes and statistics chunks depend on the batch size, so values agree to bf16
     rounding only - the default stays 1 (the reference's order).
+    `graph_streams` = n > 0 keeps the batch-1 launches (bit-identical maps in every dtype) but replays each
+    patch from a cached HIP graph (GraphedPatchHead) and rotates the patches over n streams: the host no longer
+    paces the launches and neighbouring patches fill the CUs the 32^3 / 16^3 layers leave idle.
     """
     from .parallel import shard_patches
     run = patch_fn if patch_fn is not None else _default_head(backbone, thresholds, want_evidence, want_mne)
@@ -76,6 +174,10 @@ def sliding_window_infer(x, backbone, thresholds=(), rank: int = 0, world: int =
     out = {}
     mine = list(shard_patches(len(CROPS), rank, world))
     pb = max(1, int(patch_batch))
+    if graph_streams and patch_fn is None and x.is_cuda and hasattr(backbone, "frozen_weights"):
+        _graphed_volume(x, backbone, thresholds, want_evidence, want_mne,
+                        [mine[c0:c0 + pb] for c0 in range(0, len(mine), pb)], graph_streams, out, vol)
+        mine = []
     for c0 in range(0, len(mine), pb):
         group_ids = mine[c0:c0 + pb]
         patches = [crop(x, i) for i in group_ids]

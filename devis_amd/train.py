@@ -48,6 +48,8 @@ def getArgs(argv=None):
     p.add_argument('--input_modality', default='four', type=str)
     p.add_argument('--model_name', default='U', type=str)
     p.add_argument('--test_epoch', type=int, default=199)
+    # not in the reference: BraTS val/test patches replayed from HIP graphs on this many streams (0 = eager launches)
+    p.add_argument('--graph_streams', type=int, default=0)
     p.add_argument('--compute_dtype', default='bf16', choices=['bf16', 'fp32'])
     args = p.parse_args(argv)
     args.compute_dtype = torch.bfloat16 if args.compute_dtype == 'bf16' else torch.float32
@@ -169,7 +171,7 @@ def train(args, model, optimizer, epoch, train_loader, reducer=None, log=print):
     return meter.flush()
 
 
-def predict_volume(model, x, dataset, thresholds=()):
+def predict_volume(model, x, dataset, thresholds=(), graph_streams=0):
     """The tensor part of val()/test() (trainUMIS.py:283-290, 446-461): evidence -> alpha, S, prob argmax,
     u = K/S, normalised entropy, u-threshold masks - one fused kernel after the backbone."""
     model.eval()
@@ -180,7 +182,8 @@ def predict_volume(model, x, dataset, thresholds=()):
             from .predict import sliding_window_infer
             on = dist.is_available() and dist.is_initialized()
             rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
-            return sliding_window_infer(x, model.backbone, thresholds, rank, world, want_evidence=True, want_mne=True)
+            return sliding_window_infer(x, model.backbone, thresholds, rank, world, want_evidence=True, want_mne=True,
+                                        graph_streams=graph_streams)
         logits = model.backbone(x)
         return ops.evid_infer(logits.contiguous(), False, thresholds, want_evidence=True, want_mne=True)
 
@@ -206,7 +209,7 @@ def val(args, model, current_epoch, best_dice, valid_loader, save=True):
         x, target = data[0].cuda(), data[-1].cuda()
         if args.dataset == 'BraTS':
             target = target[..., :155]
-        out = predict_volume(model, x, args.dataset)
+        out = predict_volume(model, x, args.dataset, graph_streams=getattr(args, 'graph_streams', 0))
         d = dice_per_class(out["pred"].view(-1), target.reshape(-1), args.num_classes)
         dice_total += float(np.mean(d))
     aver_dice = dice_total / max(1, len(valid_loader))
@@ -272,8 +275,9 @@ def test(args, model, test_loader, log=print):
             target = target[..., :155]
         torch.cuda.synchronize()
         t0 = time.time()
-        outs = {'clean': predict_volume(model, x, args.dataset, UEO_THRESHOLDS),
-                'noise': predict_volume(model, noised_x, args.dataset, UEO_THRESHOLDS)}
+        gs = getattr(args, 'graph_streams', 0)
+        outs = {'clean': predict_volume(model, x, args.dataset, UEO_THRESHOLDS, gs),
+                'noise': predict_volume(model, noised_x, args.dataset, UEO_THRESHOLDS, gs)}
         torch.cuda.synchronize()
         runtimes.append(time.time() - t0)
         n += 1

@@ -453,7 +453,27 @@ class Unet(nn.Module):
         key = tuple(w.data_ptr() for _, w, _ in ent) + (self.compute_dtype,)
         if self._packer is None or self._packer.key != key:
             self._packer = ops.WeightPacker(ent, self.compute_dtype, ent[0][1].device)
+            self._pack_frozen = False
+        if getattr(self, "_pack_frozen", False):
+            return self._packer.views                # frozen_weights(): packed once, read-only until it exits
         return self._packer.pack()
+
+    def frozen_weights(self):
+        """Context manager for several forwards on UNCHANGED parameters (the patches of one volume, possibly on
+        several streams or replayed from HIP graphs): the weights are packed once on the current stream on entry
+        and every forward inside reads that packing instead of rewriting it."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self._pack_frozen = False
+            self._packed(dict(self.named_parameters()))
+            self._pack_frozen = True
+            try:
+                yield self
+            finally:
+                self._pack_frozen = False
+        return cm()
 
     def forward_channels_last(self, x: Tensor) -> Tensor:
         first = self._conv_modules[0][1]                     # the network's first conv

@@ -105,7 +105,8 @@ def test_test_mode_driver_loads_checkpoint_and_reports_device_side_metrics(tmp_p
     from devis_amd import TMSU, train as T, predict as P
     from tests.util import brats_args
     torch.manual_seed(0)
-    args = brats_args(compute_dtype=torch.float32, save_dir=str(tmp_path), folder='folder0', test_epoch=3, mode='test')
+    args = brats_args(compute_dtype=torch.float32, save_dir=str(tmp_path), folder='folder0', test_epoch=3, mode='test',
+                      graph_streams=3)          # val()/test() replay the patches from HIP graphs; `want` below is eager
     m = TMSU(args)
     g = torch.Generator().manual_seed(5)
     x = torch.randn((1, 4, 240, 240, 160), generator=g)
@@ -171,3 +172,33 @@ def test_full_volume_config5_inference_vs_oracle_live():
         want = u > np.float32(t)
         d = ((um >> j) & 1).bool() != want
         assert bool(((u[d] - np.float32(t)).abs() < 1e-5).all()) and int(d.sum()) <= 1e-5 * d.numel(), (t, int(d.sum()))
+
+
+@pytest.mark.parametrize("model_name,streams", [("U", 1), ("U", 3), ("AU", 3), ("V", 3)])
+def test_graph_replayed_patches_are_bit_identical_and_follow_weight_updates(model_name, streams):
+    """sliding_window_infer(graph_streams=n): the reference's batch-1 patches replayed from HIP graphs on n
+    streams give the same maps bit for bit as the eager one-stream run, also after the parameters were updated
+    in place (the volume's weight packing happens outside the graphs), with one cached graph per stream."""
+    from devis_amd import TMSU
+    from devis_amd.predict import sliding_window_infer
+    from tests.util import brats_args
+    torch.manual_seed(0)
+    m = TMSU(brats_args(model_name=model_name, compute_dtype=torch.bfloat16)).eval()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn((1, 4, 240, 240, 160), generator=g).cuda()
+    thr = (0.05, 0.5, 0.95)
+    for round_ in range(3):
+        with torch.no_grad():
+            a = sliding_window_infer(x, m.backbone, thr, want_evidence=True)
+            b = sliding_window_infer(x, m.backbone, thr, want_evidence=True, graph_streams=streams)
+        assert sorted(a) == sorted(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (round_, k)
+        with torch.no_grad():
+            for p in m.backbone.parameters():
+                p.mul_(1.01)
+    assert len(m.backbone._devis_patch_graphs) == streams and m.backbone._pack_frozen is False
+    assert all(h.stream is not None for h in m.backbone._devis_patch_graphs.values())
+    m.train()
+    with pytest.raises(RuntimeError):
+        sliding_window_infer(x, m.backbone, thr, graph_streams=streams)

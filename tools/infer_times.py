@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--model", default="U")
 ap.add_argument("--patch-batch", type=int, default=1)
+ap.add_argument("--graph-streams", type=int, default=0)
 a = ap.parse_args()
 args = bench.brats_args(torch.bfloat16); args.model_name = a.model
 torch.manual_seed(0)
@@ -21,7 +22,7 @@ thr = (0.05, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95)      # trainUMIS
 
 def step():
     with torch.no_grad():
-        return sliding_window_infer(x, m.backbone, thr, patch_batch=a.patch_batch)
+        return sliding_window_infer(x, m.backbone, thr, patch_batch=a.patch_batch, graph_streams=a.graph_streams)
 
 for _ in range(2):
     out = step()
@@ -29,6 +30,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     out = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"workload": "configs[4]: sliding-window inference, 1 GPU, 4x240x240x160 volume = 8 patches of 128^3, model %s bf16, patch_batch %d" % (a.model, a.patch_batch),
+print(json.dumps({"workload": "configs[4]: sliding-window inference, 1 GPU, 4x240x240x160 volume = 8 patches of 128^3, model %s bf16, patch_batch %d, graph_streams %d" % (a.model, a.patch_batch, a.graph_streams),
                   "ms_per_volume": dt * 1e3, "volumes_per_s": 1 / dt, "patch_voxels_per_s": 8 * 128 ** 3 / dt,
                   "outputs": sorted(k for k, v in out.items() if v is not None)}))
