@@ -9,6 +9,7 @@ functions is differentiable by autograd - the manual backward lives in
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -23,30 +24,30 @@ def _p(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
-_stream_override = None     # raw stream handle that replaces torch's current stream (see stream_override)
+_tls = threading.local()     # .override: raw stream handle that replaces torch's current stream (see stream_override)
 
 
 def _stream() -> int:
-    if _stream_override is not None:
-        return _stream_override
+    h = getattr(_tls, "override", None)
+    if h is not None:
+        return h
     return torch.cuda.current_stream().cuda_stream
 
 
 class stream_override:
     """Launch the enclosed ops calls on `stream` (a torch.cuda.Stream) without switching torch's current stream:
-    cheaper than `with torch.cuda.stream(...)` for calls that allocate nothing (outputs and workspace given)."""
+    cheaper than `with torch.cuda.stream(...)` for calls that allocate nothing (outputs and workspace given).
+    The override is per THREAD (forward runs on the caller's thread, backward on the autograd engine's)."""
 
     def __init__(self, stream):
         self.handle = stream.cuda_stream
 
     def __enter__(self):
-        global _stream_override
-        self.prev = _stream_override
-        _stream_override = self.handle
+        self.prev = getattr(_tls, "override", None)
+        _tls.override = self.handle
 
     def __exit__(self, *exc):
-        global _stream_override
-        _stream_override = self.prev
+        _tls.override = self.prev
         return False
 
 

@@ -69,7 +69,9 @@ class FusedAdam:
 
     def _flat_grad(self) -> torch.Tensor:
         """The flat gradient buffer: the backbone's own when every .grad is the expected view of it,
-        else the gradients gathered into a buffer of this optimizer (missing gradients count as zero)."""
+        else the gradients gathered into a buffer of this optimizer.  A parameter WITHOUT a gradient is an error:
+        torch.optim.Adam skips such a parameter entirely (no decay, no moment update), which one fused launch over
+        the flat buffers cannot express; every parameter of the reference's models gets a gradient each step."""
         bb = self._backbone
         flat = getattr(bb, "last_flat_grad", None) if bb is not None else None
         if flat is not None and flat.numel() == self.total:
@@ -82,15 +84,12 @@ class FusedAdam:
         g = self._own_grad
         if self._own_views is None:
             self._own_views = [g[o:o + p.numel()].view(p.shape) for p, o in self._layout]
-        dsts, srcs = [], []
-        for (p, _), dst in zip(self._layout, self._own_views):
-            if p.grad is None:
-                dst.zero_()
-            else:
-                dsts.append(dst)
-                srcs.append(p.grad)
-        if dsts:
-            torch._foreach_copy_(dsts, srcs)          # one multi-tensor launch instead of one copy per parameter
+        if any(p.grad is None for p, _ in self._layout):
+            raise RuntimeError("FusedAdam.step(): a parameter has no gradient (torch.optim.Adam would skip it; "
+                               "FusedAdam updates every parameter in one launch) - use torch.optim.Adam for "
+                               "models with unused parameters")
+        # one multi-tensor launch instead of one copy per parameter
+        torch._foreach_copy_(self._own_views, [p.grad for p, _ in self._layout])
         return g
 
     @torch.no_grad()

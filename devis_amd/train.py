@@ -51,20 +51,34 @@ def getArgs(argv=None):
     # not in the reference: BraTS val/test patches replayed from HIP graphs on this many streams (0 = eager launches)
     p.add_argument('--graph_streams', type=int, default=0)
     p.add_argument('--compute_dtype', default='bf16', choices=['bf16', 'fp32'])
+    # not in the reference: spread the eight BraTS patches of a val/test volume over the ranks (same volume on every rank)
+    p.add_argument('--shard_patches', action='store_true')
     args = p.parse_args(argv)
     args.compute_dtype = torch.bfloat16 if args.compute_dtype == 'bf16' else torch.float32
     apply_dataset_overrides(args)
     return args
 
 
+# trainUMIS.py:1359-1386: (num_classes, out_size) the reference sets after parsing; BraTS also forces batch_size 2
+_DATASETS = {
+    'BraTS': (4, (240, 240, 160)),
+    'ISIC': (2, (224, 300)),
+    'LiTS': (3, (16, 256, 256)),
+    'DRIVE': (2, (584, 565)),
+    'TOAR': (7, (512, 512)),
+    'HC': (10, (128, 1024)),
+}
+
+
 def apply_dataset_overrides(args):
-    """Per-dataset settings the reference applies after parsing (trainUMIS.py:1359-1386)."""
+    """Per-dataset settings the reference applies after parsing (trainUMIS.py:1359-1386); an unknown dataset
+    raises NameError as there (:1384-1386)."""
+    if args.dataset not in _DATASETS:
+        print('There is no this dataset')
+        raise NameError(args.dataset)
+    args.num_classes, args.out_size = _DATASETS[args.dataset]
     if args.dataset == 'BraTS':
-        args.batch_size, args.num_classes, args.out_size = 2, 4, (240, 240, 160)
-    elif args.dataset == 'LiTS':
-        args.num_classes = getattr(args, 'num_classes', 3)
-    else:
-        args.num_classes = getattr(args, 'num_classes', 2)
+        args.batch_size = 2
     return args
 
 
@@ -171,19 +185,30 @@ def train(args, model, optimizer, epoch, train_loader, reducer=None, log=print):
     return meter.flush()
 
 
-def predict_volume(model, x, dataset, thresholds=(), graph_streams=0):
+def predict_volume(model, x, dataset, thresholds=(), graph_streams=0, shard=False, group=None):
     """The tensor part of val()/test() (trainUMIS.py:283-290, 446-461): evidence -> alpha, S, prob argmax,
-    u = K/S, normalised entropy, u-threshold masks - one fused kernel after the backbone."""
+    u = K/S, normalised entropy, u-threshold masks - one fused kernel after the backbone.
+
+    `shard=True` (BraTS only) spreads the eight patches of THIS volume over the ranks of `group`
+    and gathers the maps on every rank.  It is opt-in because it is only right when every rank passes the SAME
+    volume: with a DistributedSampler on the loader each rank holds another subject, and stitching their patches
+    would give a chimera without any error.  A cheap checksum of x is compared across ranks to catch that."""
     model.eval()
     with torch.no_grad():
         if dataset == 'BraTS':
-            # eight patches, sharded over the ranks when torch.distributed is up (SURVEY.md §8e)
             import torch.distributed as dist
             from .predict import sliding_window_infer
-            on = dist.is_available() and dist.is_initialized()
-            rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
-            return sliding_window_infer(x, model.backbone, thresholds, rank, world, want_evidence=True, want_mne=True,
-                                        graph_streams=graph_streams)
+            on = shard and dist.is_available() and dist.is_initialized()
+            rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
+            if on and world > 1:
+                chk = x.double().sum().reshape(1)
+                lo, hi = chk.clone(), chk.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+                if lo.item() != hi.item():
+                    raise ValueError("predict_volume(shard=True): the ranks hold different volumes")
+            return sliding_window_infer(x, model.backbone, thresholds, rank, world, group=group, want_evidence=True,
+                                        want_mne=True, graph_streams=graph_streams)
         logits = model.backbone(x)
         return ops.evid_infer(logits.contiguous(), False, thresholds, want_evidence=True, want_mne=True)
 
@@ -199,9 +224,33 @@ def dice_per_class(pred, target, num_classes):
     return out
 
 
+def dice_isic_from_counts(conf):
+    """predict.py:426-437 (`Dice_isic` on one-hot prediction and target) from the K x K confusion counts
+    conf[target, pred]: mean over classes 1..K-1 of 2*|p&t| / (|t| + |p| + 1), in fp32 like the reference."""
+    conf = np.asarray(conf)
+    inter = np.diag(conf).astype(np.float32)
+    ref_vol = conf.sum(1).astype(np.float32)
+    seg_vol = conf.sum(0).astype(np.float32)
+    dice = np.float32(2.0) * inter / (ref_vol + seg_vol + np.float32(1.0))
+    return float(np.mean(dice[1:], dtype=np.float32))
+
+
+def selection_dice(conf, dataset):
+    """The dice val() accumulates into `aver_dice`, i.e. what decides `best_dice` and the checkpoint trigger
+    (trainUMIS.py:294-310): BraTS -> softmax_output_dice(...)[1] (tumour core {1,3}), LiTS ->
+    softmax_output_litsdice(...)[0] (liver {1,2}), every other dataset -> Dice_isic."""
+    from .predict import softmax_output_dice, softmax_output_litsdice
+    if dataset == 'BraTS':
+        return softmax_output_dice(conf)[1]
+    if dataset == 'LiTS':
+        return softmax_output_litsdice(conf)[0]
+    return dice_isic_from_counts(conf)
+
+
 def val(args, model, current_epoch, best_dice, valid_loader, save=True):
-    """trainUMIS.py:265-331: argmax(alpha/S) + dice; checkpoint {'epoch','state_dict'} with the reference's
-    file name and trigger rule (:314-330)."""
+    """trainUMIS.py:265-331: argmax(alpha/S), the dataset's selection dice (`selection_dice`), checkpoint
+    {'epoch','state_dict'} with the reference's file name and trigger rule (:314-330).  In a process group only
+    rank 0 writes the file."""
     model.eval()
     meter = AverageMeter()
     dice_total = 0.0
@@ -209,16 +258,19 @@ def val(args, model, current_epoch, best_dice, valid_loader, save=True):
         x, target = data[0].cuda(), data[-1].cuda()
         if args.dataset == 'BraTS':
             target = target[..., :155]
-        out = predict_volume(model, x, args.dataset, graph_streams=getattr(args, 'graph_streams', 0))
-        d = dice_per_class(out["pred"].view(-1), target.reshape(-1), args.num_classes)
-        dice_total += float(np.mean(d))
+        out = predict_volume(model, x, args.dataset, graph_streams=getattr(args, 'graph_streams', 0),
+                             shard=getattr(args, 'shard_patches', False))
+        conf = ops.eval_counts(out["pred"].reshape(-1), target.reshape(-1).contiguous(), args.num_classes)["conf"]
+        dice_total += selection_dice(conf.cpu().numpy(), args.dataset)
     aver_dice = dice_total / max(1, len(valid_loader))
     if aver_dice > best_dice \
             or (current_epoch + 1) % int(args.end_epochs - 1) == 0 \
             or (current_epoch + 1) % int(args.end_epochs - 2) == 0 \
             or (current_epoch + 1) % int(args.end_epochs - 3) == 0:
         best_dice = aver_dice
-        if save:
+        import torch.distributed as dist
+        rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+        if save and rank0:
             tag = '_DUloss' if args.Uncertainty_Loss else ''
             name = '%s_%s_%s%s_epoch_%d.pth' % (args.model_name, args.dataset, args.folder, tag, current_epoch)
             os.makedirs(args.save_dir, exist_ok=True)
@@ -276,8 +328,9 @@ def test(args, model, test_loader, log=print):
         torch.cuda.synchronize()
         t0 = time.time()
         gs = getattr(args, 'graph_streams', 0)
-        outs = {'clean': predict_volume(model, x, args.dataset, UEO_THRESHOLDS, gs),
-                'noise': predict_volume(model, noised_x, args.dataset, UEO_THRESHOLDS, gs)}
+        sh = getattr(args, 'shard_patches', False)
+        outs = {'clean': predict_volume(model, x, args.dataset, UEO_THRESHOLDS, gs, shard=sh),
+                'noise': predict_volume(model, noised_x, args.dataset, UEO_THRESHOLDS, gs, shard=sh)}
         torch.cuda.synchronize()
         runtimes.append(time.time() - t0)
         n += 1

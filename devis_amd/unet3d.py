@@ -354,6 +354,13 @@ class _Unet3dFn(torch.autograd.Function):
         flat, run.G = model._grad_views(dlogits.device)
         run.sync = model._grad_sync
         if run.sync is not None:
+            # the reducer averages the flat buffer in place and .grad must BE that buffer: a .grad left over from an
+            # earlier backward (gradient accumulation, zero_grad(set_to_none=False)) would be summed by autograd with
+            # an un-reduced copy - refuse instead of training on wrong gradients
+            if any(p.grad is not None for p in model.parameters()):
+                raise RuntimeError("data-parallel backward needs .grad = None on every backbone parameter "
+                                   "(call optimizer.zero_grad() / zero_grad(set_to_none=True) first); gradient "
+                                   "accumulation is not supported with the overlapped all-reduce")
             run.sync.begin(flat, model._bucket_bounds)
         dx_cl = run.backward(dlogits.contiguous(), ctx.need_dx)
         dx = ops.from_channels_last(dx_cl) if dx_cl is not None else None
