@@ -16,7 +16,8 @@ LABEL_I64, LABEL_U8, LABEL_I32 = 0, 1, 2
 EVID_MAX_K = 8
 EVID_SCAL_FLOATS = 4 + 3 * EVID_MAX_K
 
-_STATUS = {-1: "bad argument", -2: "unsupported shape", -3: "HIP error", -4: "workspace too small"}
+_STATUS = {-1: "bad argument", -2: "unsupported shape", -3: "HIP error", -4: "workspace too small",
+           -5: "input exceeds the fixed scratch of the no-allocation entry point (N <= 1024 samples)"}
 
 
 class DevisError(RuntimeError):
@@ -99,6 +100,7 @@ SIGNATURES = {
     "devis_maxpool2d_bwd_add": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "devis_evid_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "devis_evid_loss_fwd": (_I, [_P, _I64, _I64, _I64, _I, _P, _I, _I64, _I64, _I64, _F, _P, _P, _P, _P, _SZ, _P]),
+    "devis_evid_loss_fwd_noalloc": (_I, [_P, _I64, _I64, _I64, _I, _P, _I, _I64, _I64, _I64, _F, _P, _P, _P, _P]),
     "devis_evid_loss_bwd": (_I, [_P, _I64, _I64, _I64, _I, _P, _I, _I64, _I64, _I64, _F, _P, _P, _P, _P, _P, _P, _P]),
     "devis_evid_crit_fwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     "devis_evid_crit_bwd": (_I, [_EP, _P, _I64, _I64, _I64, _I, _P, _P, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P]),

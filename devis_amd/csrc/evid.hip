@@ -4,12 +4,20 @@
 //   inference:     z   -> evidence, argmax mask, u = K/S, entropy map, u-threshold bit masks
 // digamma / trigamma / lgamma are evaluated in registers (argument >= 1 always: alpha = softplus+1).
 #include "common.h"
-
-namespace devis {
+#include <mutex>
 
 #define EV_MAXK DEVIS_EVID_MAX_K
 #define EV_BLOCKS 1024
 #define EV_NACC (1 + 3 * EV_MAXK)
+
+// Scratch of the one entry point that allocates nothing (devis_evid_loss_fwd_noalloc, bottom of this file): the
+// per-block fp64 partial sums of k_crit_fwd, which the other entry points take from the caller's workspace.
+// Every GPU the library runs on holds its own copy of this array until the process ends (200 KB).  In host code
+// the NAME is only a handle for hipGetSymbolAddress; kernels are given the resolved per-device pointer.
+#define EV_SCRATCH_BYTES (EV_BLOCKS * EV_NACC * sizeof(double))
+static __device__ __align__(256) unsigned char scratch[EV_SCRATCH_BYTES];
+
+namespace devis {
 
 __device__ __forceinline__ float softplus_f(float z) { return z > 20.f ? z : log1pf(expf(z)); }
 // d softplus / dz exactly as torch's softplus_backward: exp(z)/(exp(z)+1), 1 above the threshold
@@ -717,6 +725,46 @@ int devis_evid_loss_bwd(const void* logits, int64_t sN, int64_t sV, int64_t sK, 
   const devis_evid_params p = {CRIT_DCE, 0, 0, lambda, 0.f, 0.f};
   return devis_evid_crit_bwd(&p, logits, sN, sV, sK, dtype, nullptr, labels, label_dtype, N, V, K, scal, grad_loss,
                              grad_pv, grad_dice, grad_ev, dlogits, nullptr, stream);
+}
+
+// ---- the entry point for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc): devis_evid_loss_fwd with the partial sums in the file-scope `scratch` array instead of a workspace.
+#define EV_MAX_DEVICES 64
+static void* g_scratch_ptr[EV_MAX_DEVICES];     // device address of `scratch` on device i, resolved on first use
+static std::mutex g_scratch_mu;
+
+// -> the address of the CURRENT device's copy of `scratch` (each GPU has its own copy at its own address)
+static int scratch_of_current_device(void** out) {
+  int dev = -1;
+  int rc = check_hip(hipGetDevice(&dev));
+  if (rc) return rc;
+  if (dev < 0 || dev >= EV_MAX_DEVICES) return DEVIS_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    rc = check_hip(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (rc) return rc;
+    if (!ptr) { g_last_hip_error = (int)hipErrorInvalidSymbol; return DEVIS_ERR_HIP; }
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return DEVIS_OK;
+}
+
+int devis_evid_loss_fwd_noalloc(const void* logits, int64_t sN, int64_t sV, int64_t sK, int dtype, const void* labels,
+                                int label_dtype, int64_t N, int64_t V, int64_t K, float lambda, float* evidence_out,
+                                float* per_voxel_out, float* scal, void* stream) {
+  if (!scal) return DEVIS_ERR_BAD_ARG;
+  // the fixed scratch holds EV_BLOCKS block partials: enough for any V, and for N <= EV_BLOCKS samples
+  static_assert(DEVIS_EVID_NOALLOC_MAX_N == EV_BLOCKS, "header limit and scratch size must agree");
+  if (N > DEVIS_EVID_NOALLOC_MAX_N || devis_evid_workspace_bytes(N, V, K) > EV_SCRATCH_BYTES) return DEVIS_ERR_SCRATCH_LIMIT;
+  void* ptr = nullptr;
+  const int rc = scratch_of_current_device(&ptr);
+  if (rc) return rc;
+  // Nothing in the scratch has to start at zero: every block of k_crit_fwd overwrites its own slot and
+  // k_evid_finalize reads exactly the slots of this launch, so the previous call's contents are never seen.
+  return devis_evid_loss_fwd(logits, sN, sV, sK, dtype, labels, label_dtype, N, V, K, lambda, evidence_out,
+                             per_voxel_out, scal, ptr, EV_SCRATCH_BYTES, stream);
 }
 
 int devis_evid_infer(const void* logits, int64_t sN, int64_t sV, int64_t sK, int dtype, int64_t N, int64_t V, int64_t K,

@@ -35,7 +35,8 @@ enum devis_status {
   DEVIS_ERR_BAD_ARG = -1,
   DEVIS_ERR_UNSUPPORTED = -2,
   DEVIS_ERR_HIP = -3,
-  DEVIS_ERR_WORKSPACE = -4
+  DEVIS_ERR_WORKSPACE = -4,
+  DEVIS_ERR_SCRATCH_LIMIT = -5 /* input exceeds the fixed scratch of a no-allocation entry point */
 };
 enum devis_dtype { DEVIS_F32 = 0, DEVIS_BF16 = 1 };
 enum devis_label_dtype { DEVIS_LABEL_I64 = 0, DEVIS_LABEL_U8 = 1, DEVIS_LABEL_I32 = 2 };
@@ -249,6 +250,21 @@ int devis_evid_loss_fwd(const void* logits, int64_t sN, int64_t sV, int64_t sK, 
                         const void* labels, int label_dtype, int64_t N, int64_t V, int64_t K,
                         float lambda, float* evidence_out, float* per_voxel_out, float* scal,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* devis_evid_loss_fwd for callers that CANNOT ALLOCATE.  It has no counterpart in the reference; it exists for
+ * callers that cannot call hipMalloc or size a workspace: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Same arguments, kernels and results as devis_evid_loss_fwd, minus the
+ * workspace: the per-block partial sums live in a fixed 200 KB `__device__` array inside the library (one copy per
+ * GPU, held until the process ends).  Limit: N <= DEVIS_EVID_NOALLOC_MAX_N samples (any V, K <= DEVIS_EVID_MAX_K);
+ * beyond it the call returns DEVIS_ERR_SCRATCH_LIMIT and launches nothing.  It calls no hipMalloc / hipFree.  The
+ * device that owns `stream` must be current.  All calls on one GPU share that GPU's array: calls that overlap on
+ * one GPU (two streams, two threads) race on it - serialise them, or use devis_evid_loss_fwd with a workspace per
+ * stream.  The first call on a device resolves the array's address (hipGetSymbolAddress): make it once outside
+ * any graph capture. */
+#define DEVIS_EVID_NOALLOC_MAX_N 1024
+int devis_evid_loss_fwd_noalloc(const void* logits, int64_t sN, int64_t sV, int64_t sK, int dtype,
+                                const void* labels, int label_dtype, int64_t N, int64_t V, int64_t K,
+                                float lambda, float* evidence_out, float* per_voxel_out, float* scal,
+                                void* stream);
 /* dlogits (same strides/dtype as logits) = grad_loss * dloss/dz  [+ grad_evidence * sigmoid(z)]
  * grad_loss: device pointer to one fp32;  grad_evidence: optional NC(D)HW fp32.
  * grad_per_voxel: optional [N*V] fp32 upstream gradient of the (NV,1) tensor (then grad_loss is
