@@ -2,6 +2,7 @@
 from .unet3d import Unet                      # noqa: F401
 from .attunet3d import AttUnet                # noqa: F401
 from .vnet3d import VNet                      # noqa: F401
+from .vnet2d import VNet2D                    # noqa: F401
 from .unet2d import Unet2D, Unet2DDRIVE       # noqa: F401
 from .trustworthy_seg import TMSU             # noqa: F401
 from .predict import tailor_and_concat        # noqa: F401

@@ -40,81 +40,73 @@ __device__ __forceinline__ float dsoftplus_fast(float z) {
   return z > 20.f ? 1.f : t * __builtin_amdgcn_rcpf(t + 1.f);
 }
 
-// ---- special functions on x >= 1 (alpha = softplus + 1 and sums of alphas), branch-free:
-// arguments below 6 are shifted up by 6 with ONE reciprocal / ONE extra log,
-//   sum_{i<6} 1/(x+i) = P'(x)/P(x),  sum_{i<6} log(x+i) = log P(x),  P(x) = x(x+1)...(x+5),
-// then the asymptotic series at X >= 6 (truncation < 1e-9).  Hardware rcp/log (1 ulp) are used: their
-// error is below the fp32 rounding of the terms they feed.
+// ---- special functions on x >= 1 (alpha = softplus + 1 and sums of alphas): no argument shift, no branch.
+// With t = 1/x in (0, 1]:
+//   psi(x)      = ln x - t/2 + t^2 * P(t)                           (P -> -1/12 + t^2/120 - ...)
+//   ln Gamma(x) = (x - 1/2) ln x - x + ln(2 pi)/2 + t * Q(t)         (Q ->  1/12 - t^2/360 + ...)
+//   psi'(x)     = t * (1 + t * (1/2 + t * R(t)))                     (R ->  1/6  - t^2/30  + ...)
+// P, Q (degree 5) and R (degree 6) are weighted minimax fits on the whole of (0, 1] to the remainders of the
+// Stirling series (fitted against mpmath at 40 digits, tools/fit_special.py): |psi error| < 2.9e-8,
+// |lnGamma error| < 1.8e-8, relative psi' error < 3.6e-8 before fp32 rounding (half an fp32 ulp of a value of
+// order one, which is what fp32 arithmetic on these functions leaves anyway) - one reciprocal and one logarithm per
+// argument (hardware rcp / log2, 1 ulp), where the shift-by-6 recurrence of round 1 needed two of each plus twice
+// the multiplies.  The kernels here are bound by the vector ALU, not by HBM, so this is where their time goes.
 __device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
 // raw v_log_f32 (log2) * ln 2: every argument here is >= 1, so __logf's denormal-range rescaling (five extra
-// instructions per call) is dead weight in kernels whose limit is the vector ALU
+// instructions per call) is dead weight
 __device__ __forceinline__ float log_f(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
 __device__ __forceinline__ float exp_f(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
-// psi(x) and ln Gamma(x) together (they share P, 1/X and log X)
-__device__ __forceinline__ void psi_lgamma_f(float x, float& psi, float& lg) {
-  const bool small = x < 6.f;
-  const float xs = small ? x : 1.f;
-  const float a0 = xs * (xs + 1.f), a1 = (xs + 2.f) * (xs + 3.f), a2 = (xs + 4.f) * (xs + 5.f);
-  const float b0 = 2.f * xs + 1.f, b1 = 2.f * xs + 5.f, b2 = 2.f * xs + 9.f;
-  const float P = a0 * a1 * a2;
-  const float num = fmaf(b0, a1 * a2, fmaf(b1, a0 * a2, b2 * a0 * a1));
-  const float X = small ? x + 6.f : x;
-  const float xi = rcp_f(X), x2 = xi * xi, lx = log_f(X);
-  const float pser = x2 * (8.3333333333e-2f - x2 * (8.3333333333e-3f - x2 * (3.9682539683e-3f - x2 * (4.1666666667e-3f - x2 * 7.5757575758e-3f))));
-  const float lser = xi * (8.3333333333e-2f - x2 * (2.7777777778e-3f - x2 * (7.9365079365e-4f - x2 * 5.9523809524e-4f)));
-  psi = (lx - 0.5f * xi - pser) - (small ? num * rcp_f(P) : 0.f);
-  lg = ((X - 0.5f) * lx - X + 0.91893853320467f + lser) - (small ? log_f(P) : 0.f);
+__device__ __forceinline__ float psi_rem(float t) {      // P(t), degree 5
+  float r = 3.2940332945e-04f;
+  r = fmaf(r, t, -2.8618493519e-04f);
+  r = fmaf(r, t, -3.3689002729e-03f);
+  r = fmaf(r, t, 9.6790001597e-03f);
+  r = fmaf(r, t, -2.5322229087e-04f);
+  return fmaf(r, t, -8.3315732563e-02f);
 }
-// two arguments at once (written on 2-vectors; the build compiles packed fp32 instructions out, see build.sh, so
-// these become pairs of scalar FMAs with the shared control flow of one call)
+__device__ __forceinline__ float lgamma_rem(float t) {   // Q(t), degree 5
+  float r = -1.5870583415e-04f;
+  r = fmaf(r, t, 4.1252054178e-04f);
+  r = fmaf(r, t, 3.6647560987e-04f);
+  r = fmaf(r, t, -2.9122530426e-03f);
+  r = fmaf(r, t, 2.1162378472e-05f);
+  return fmaf(r, t, 8.3332249886e-02f);
+}
+__device__ __forceinline__ float trigamma_rem(float t) { // R(t), degree 6
+  float r = 3.1959869627e-03f;
+  r = fmaf(r, t, -1.2391032702e-02f);
+  r = fmaf(r, t, 1.3949583783e-02f);
+  r = fmaf(r, t, 9.7518234909e-03f);
+  r = fmaf(r, t, -3.6750482461e-02f);
+  r = fmaf(r, t, 5.4306552782e-04f);
+  return fmaf(r, t, 1.6663515729e-01f);
+}
+// from t = 1/x and lx = ln x
+__device__ __forceinline__ float psi_from(float t, float lx) { return fmaf(t * t, psi_rem(t), fmaf(-0.5f, t, lx)); }
+__device__ __forceinline__ float lgamma_from(float x, float t, float lx) {
+  return fmaf(t, lgamma_rem(t), fmaf(x - 0.5f, lx, 0.91893853320467f - x));
+}
+// psi(x) and ln Gamma(x) together (they share 1/x and ln x)
+__device__ __forceinline__ void psi_lgamma_f(float x, float& psi, float& lg) {
+  const float t = rcp_f(x), lx = log_f(x);
+  psi = psi_from(t, lx);
+  lg = lgamma_from(x, t, lx);
+}
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void psi_lgamma_f2(f32x2 x, f32x2& psi, f32x2& lg) {
-  const bool s0 = x.x < 6.f, s1 = x.y < 6.f;
-  const f32x2 xs = {s0 ? x.x : 1.f, s1 ? x.y : 1.f};
-  const f32x2 a0 = xs * (xs + 1.f), a1 = (xs + 2.f) * (xs + 3.f), a2 = (xs + 4.f) * (xs + 5.f);
-  const f32x2 b0 = 2.f * xs + 1.f, b1 = 2.f * xs + 5.f, b2 = 2.f * xs + 9.f;
-  const f32x2 a12 = a1 * a2;
-  const f32x2 P = a0 * a12;
-  const f32x2 num = b0 * a12 + (b1 * (a0 * a2) + b2 * (a0 * a1));
-  const f32x2 X = {s0 ? x.x + 6.f : x.x, s1 ? x.y + 6.f : x.y};
-  const f32x2 xi = {rcp_f(X.x), rcp_f(X.y)}, x2 = xi * xi, lx = {log_f(X.x), log_f(X.y)};
-  const f32x2 pser = x2 * (8.3333333333e-2f - x2 * (8.3333333333e-3f - x2 * (3.9682539683e-3f - x2 * (4.1666666667e-3f - x2 * 7.5757575758e-3f))));
-  const f32x2 lser = xi * (8.3333333333e-2f - x2 * (2.7777777778e-3f - x2 * (7.9365079365e-4f - x2 * 5.9523809524e-4f)));
-  const f32x2 rP = {rcp_f(P.x), rcp_f(P.y)}, lP = {log_f(P.x), log_f(P.y)};
-  const f32x2 corr_p = num * rP;
-  const f32x2 p0 = lx - 0.5f * xi - pser, l0 = (X - 0.5f) * lx - X + 0.91893853320467f + lser;
-  psi = (f32x2){p0.x - (s0 ? corr_p.x : 0.f), p0.y - (s1 ? corr_p.y : 0.f)};
-  lg = (f32x2){l0.x - (s0 ? lP.x : 0.f), l0.y - (s1 ? lP.y : 0.f)};
+  float p0, l0, p1, l1;
+  psi_lgamma_f(x.x, p0, l0);
+  psi_lgamma_f(x.y, p1, l1);
+  psi = (f32x2){p0, p1};
+  lg = (f32x2){l0, l1};
 }
-__device__ __forceinline__ float digamma_f(float x) {
-  const bool small = x < 6.f;
-  const float xs = small ? x : 1.f;
-  const float a0 = xs * (xs + 1.f), a1 = (xs + 2.f) * (xs + 3.f), a2 = (xs + 4.f) * (xs + 5.f);
-  const float b0 = 2.f * xs + 1.f, b1 = 2.f * xs + 5.f, b2 = 2.f * xs + 9.f;
-  const float num = fmaf(b0, a1 * a2, fmaf(b1, a0 * a2, b2 * a0 * a1));
-  const float X = small ? x + 6.f : x;
-  const float xi = rcp_f(X), x2 = xi * xi;
-  const float pser = x2 * (8.3333333333e-2f - x2 * (8.3333333333e-3f - x2 * (3.9682539683e-3f - x2 * (4.1666666667e-3f - x2 * 7.5757575758e-3f))));
-  return (log_f(X) - 0.5f * xi - pser) - (small ? num * rcp_f(a0 * a1 * a2) : 0.f);
-}
-__device__ __forceinline__ float lgamma_f(float x) {
-  float psi, lg;
-  psi_lgamma_f(x, psi, lg);
-  return lg;
-}
+__device__ __forceinline__ float digamma_f(float x) { return psi_from(rcp_f(x), log_f(x)); }
+__device__ __forceinline__ float lgamma_f(float x) { return lgamma_from(x, rcp_f(x), log_f(x)); }
 // psi'(x), x >= 1
 __device__ __forceinline__ float trigamma_f(float x) {
-  const bool small = x < 6.f;
-  const float xs = small ? x : 1.f;
-  float r = 0.f;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { const float t = rcp_f(xs + (float)i); r = fmaf(t, t, r); }
-  const float X = small ? x + 6.f : x;
-  const float xi = rcp_f(X), x2 = xi * xi;
-  // 1/x + 1/(2x^2) + 1/(6x^3) - 1/(30x^5) + 1/(42x^7) - 1/(30x^9) + 5/(66 x^11)
-  const float ser = xi * (1.f + xi * 0.5f + x2 * (1.6666666667e-1f - x2 * (3.3333333333e-2f - x2 * (2.3809523810e-2f - x2 * (3.3333333333e-2f - x2 * 7.5757575758e-2f)))));
-  return ser + (small ? r : 0.f);
+  const float t = rcp_f(x);
+  return t * fmaf(t, fmaf(t, trigamma_rem(t), 0.5f), 1.f);
 }
 
 __device__ __forceinline__ int load_label(const void* labels, int ldt, int64_t i) {
@@ -374,35 +366,55 @@ __host__ __device__ inline Tversky tversky(double TP, double FP, double FN) {
   return t;
 }
 
-__global__ void k_evid_finalize(const double* __restrict__ partial, int blocks, int K, double NV, int kind, float a_au,
-                                float* __restrict__ scal) {
-  // 1024 threads: accumulator i = tid % 32, block slice = tid / 32; slices combined in a fixed order
+// 1024 threads.  Thread t owns block row t (t, t + 1024, ... when there are more rows): its loads of the used
+// accumulators are independent (all in flight at once), the rows combine in an fp64 xor tree per wave and the 16
+// waves in wave order through LDS - a fixed order, so the result does not depend on the launch.  The K dice terms
+// (fp64 log) are evaluated by K threads side by side.
+__global__ void __launch_bounds__(1024)
+k_evid_finalize(const double* __restrict__ partial, int blocks, int K, double NV, int kind, float a_au,
+                float* __restrict__ scal) {
+  __shared__ double red[16][EV_NACC];
   __shared__ double tot[EV_NACC];
-  __shared__ double red[32][32];
-  {
-    const int i = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    double a = 0.0;
-    if (i < EV_NACC)
-      for (int b = sl; b < blocks; b += 32) a += partial[(int64_t)b * EV_NACC + i];
-    red[sl][i] = a;
+  __shared__ double dterm[EV_MAXK];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  double a[EV_NACC];
+#pragma unroll
+  for (int i = 0; i < EV_NACC; ++i) a[i] = 0.0;
+  for (int b = t; b < blocks; b += 1024) {
+    const double* row = partial + (int64_t)b * EV_NACC;
+#pragma unroll
+    for (int i = 0; i < EV_NACC; ++i)
+      if (i == 0 || (i - 1) % EV_MAXK < K) a[i] += row[i];
   }
-  __syncthreads();
-  if (threadIdx.x < EV_NACC) {
-    double a = 0.0;
-    for (int sl = 0; sl < 32; ++sl) a += red[sl][threadIdx.x];
-    tot[threadIdx.x] = a;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double dice = 0.0;
-    for (int k = 0; k < K; ++k) {
-      const double s0 = tot[1 + k], s1 = tot[1 + EV_MAXK + k], s2 = tot[1 + 2 * EV_MAXK + k];
-      if (kind == CRIT_DCE) dice += -log((2.0 * s0 + 1e-5) / (s2 + s1 + 1.0 + 1e-5));
-      if (kind == CRIT_DCEU) dice += 1.0 - tversky(s0, s1, s2).dice;
-      scal[4 + k] = (float)s0;
-      scal[4 + K + k] = (float)s1;
-      scal[4 + 2 * K + k] = (float)s2;
+#pragma unroll
+  for (int i = 0; i < EV_NACC; ++i) {
+    if (i == 0 || (i - 1) % EV_MAXK < K) {       // K is uniform: no divergence
+      const double w = wave_sum(a[i]);
+      if (lane == 0) red[wave][i] = w;
     }
+  }
+  __syncthreads();
+  if (t < EV_NACC) {
+    double s = 0.0;
+    if (t == 0 || (t - 1) % EV_MAXK < K)
+      for (int w = 0; w < 16; ++w) s += red[w][t];
+    tot[t] = s;
+  }
+  __syncthreads();
+  if (t < K) {
+    const double s0 = tot[1 + t], s1 = tot[1 + EV_MAXK + t], s2 = tot[1 + 2 * EV_MAXK + t];
+    double d = 0.0;
+    if (kind == CRIT_DCE) d = -log((2.0 * s0 + 1e-5) / (s2 + s1 + 1.0 + 1e-5));
+    if (kind == CRIT_DCEU) d = 1.0 - tversky(s0, s1, s2).dice;
+    dterm[t] = d;
+    scal[4 + t] = (float)s0;
+    scal[4 + K + t] = (float)s1;
+    scal[4 + 2 * K + t] = (float)s2;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double dice = 0.0;
+    for (int k = 0; k < K; ++k) dice += dterm[k];
     dice /= (double)K;
     const double mean_pv = tot[0] / NV;
     const double wd = kind == CRIT_DCEU ? 1.0 - (double)a_au : 1.0;     // criterions.py:417
@@ -567,6 +579,194 @@ k_crit_bwd(const T* __restrict__ in, EvidShape s, const float* __restrict__ ev_i
   }
 }
 
+// ------------------------------------------- the training hot path: K = 4, logits in, channels-last rows
+// devis_evid_loss_fwd / _bwd on the 3-D U-Net's endconv output (TrustworthySeg.py:144-155 + criterions.py:421-456).
+// Same arithmetic as k_crit_fwd / k_crit_bwd<T, CRIT_DCE, 4>, written straight-line: one vector load per voxel,
+// no per-class branches, no scratch, two voxels in flight per thread, the label counts R_k taken with wave-wide
+// ballots on the scalar unit.  Vector-ALU budget per voxel: 20 transcendentals (4 exp2 + 4 log2 for softplus,
+// one rcp + one log2 for each of alpha_0..3, S~, S) + about 230 fused multiply-adds.
+
+// softplus(z) = max(z, 0) + log1p(exp(-|z|)); t = exp(-|z|) in (0, 1], u = fl(1 + t).  Equal to torch's
+// thresholded form (z for z > 20) to within 2e-9 relative.  log1p(t) = ln(u) + d / u with d = t - (u - 1) the
+// rounding error of u (exact in fp32); d / u is replaced by d: the difference d t / u is below 6e-8 t, so tiny
+// evidences keep their relative accuracy (u = 1 gives exactly t) without a branch or a select.
+__device__ __forceinline__ float softplus_tu(float z, float& t, float& u) {
+  t = __builtin_amdgcn_exp2f(fabsf(z) * -1.4426950408889634f);
+  u = 1.f + t;
+  const float l1p = fmaf(__builtin_amdgcn_logf(u), 0.69314718055994531f, t - (u - 1.f));
+  return fmaxf(z, 0.f) + l1p;
+}
+
+template <int LDT> __device__ __forceinline__ int label_at(const void* labels, int64_t i) {
+  if (LDT == DEVIS_LABEL_I64) return ((const int*)labels)[2 * i];      // low half: class indices are tiny
+  if (LDT == DEVIS_LABEL_U8) return (int)((const uint8_t*)labels)[i];
+  return ((const int32_t*)labels)[i];
+}
+
+// per-voxel term L_ace + lambda * KL and the evidence of one voxel
+__device__ __forceinline__ float dce4_voxel(const float* z, int y, float lambda, float lgK, float* e) {
+  float al[4], tk[4], lk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t, u;
+    e[k] = softplus_tu(z[k], t, u);
+    al[k] = e[k] + 1.f;
+  }
+  const float S = (al[0] + al[1]) + (al[2] + al[3]);
+  float e_y = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) e_y = (y == k) ? e[k] : e_y;
+  const float St = S - e_y;                    // strength of alpha~ (label class reset to 1)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { tk[k] = rcp_f(al[k]); lk[k] = log_f(al[k]); }
+  const float tS = rcp_f(S), lS = log_f(S), tT = rcp_f(St), lT = log_f(St);
+  const float psiS = psi_from(tS, lS), psiT = psi_from(tT, lT), lgT = lgamma_from(St, tT, lT);
+  float psi_y = 0.f, sum_lg = 0.f, kl = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float ps = psi_from(tk[k], lk[k]), lg = lgamma_from(al[k], tk[k], lk[k]);
+    const bool lab = (y == k);
+    psi_y = lab ? ps : psi_y;
+    sum_lg += lab ? 0.f : lg;
+    kl = lab ? kl : fmaf(e[k], ps - psiT, kl);
+  }
+  if (y < 0 || y > 3) psi_y = psi_from(1.f, 0.f);          // no class matched: alpha_y = 1, as k_crit_fwd has it
+  return fmaf(lambda, (lgT - sum_lg - lgK) + kl, psiS - psi_y);
+}
+
+template <typename T, int LDT, bool EVOUT, bool PVOUT>
+__global__ void __launch_bounds__(256)
+k_dce4_fwd(const T* __restrict__ z, const void* __restrict__ labels, int64_t V, float lambda,
+           float* __restrict__ evidence_out, float* __restrict__ per_voxel_out, double* __restrict__ partial) {
+  const float lgK = 1.791759469228055f;                    // ln Gamma(4) = ln 6
+  const int64_t n = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const T* zn = z + n * V * 4;
+  float apv = 0.f, aI[4] = {0.f, 0.f, 0.f, 0.f}, aP[4] = {0.f, 0.f, 0.f, 0.f};
+  int rc[4] = {0, 0, 0, 0};                                 // wave-uniform label counts
+  for (int64_t v0 = (int64_t)blockIdx.x * 256 + threadIdx.x; v0 < V; v0 += 2 * stride) {
+    const int64_t v1 = v0 + stride;
+    const bool two = v1 < V;
+    float za[4], zb[4] = {0.f, 0.f, 0.f, 0.f};
+    load4(zn + v0 * 4, za);
+    const int ya = label_at<LDT>(labels, n * V + v0);
+    int yb = -1;
+    if (two) { load4(zn + v1 * 4, zb); yb = label_at<LDT>(labels, n * V + v1); }
+    float ea[4], eb[4];
+    const float pa = dce4_voxel(za, ya, lambda, lgK, ea);
+    float pb = dce4_voxel(zb, yb, lambda, lgK, eb);
+    if (!two) { pb = 0.f; eb[0] = eb[1] = eb[2] = eb[3] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (EVOUT) {
+        evidence_out[(n * 4 + k) * V + v0] = ea[k];
+        if (two) evidence_out[(n * 4 + k) * V + v1] = eb[k];
+      }
+      aI[k] += ((ya == k) ? ea[k] : 0.f) + ((yb == k) ? eb[k] : 0.f);
+      aP[k] += ea[k] + eb[k];
+      rc[k] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ya == k)) +
+               __builtin_popcountll(__builtin_amdgcn_ballot_w64(yb == k));
+    }
+    if (PVOUT) {
+      per_voxel_out[n * V + v0] = pa;
+      if (two) per_voxel_out[n * V + v1] = pb;
+    }
+    apv += pa + pb;
+  }
+  if (!partial) return;
+  __shared__ double red[4][13];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {
+    const double w = wave_sum((double)apv);
+    if (lane == 0) red[wave][0] = w;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double wi = wave_sum((double)aI[k]), wp = wave_sum((double)aP[k]);
+    if (lane == 0) { red[wave][1 + k] = wi; red[wave][5 + k] = wp; red[wave][9 + k] = (double)rc[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < EV_NACC) {
+    // slot i of this block's row: 0 = per-voxel sum, 1 + k = I_k, 1 + MAXK + k = P_k, 1 + 2 MAXK + k = R_k
+    const int i = threadIdx.x, grp = i == 0 ? -1 : (i - 1) / EV_MAXK, k = i == 0 ? 0 : (i - 1) % EV_MAXK;
+    double s = 0.0;
+    if (i == 0 || k < 4) {
+      const int j = i == 0 ? 0 : 1 + 4 * grp + k;
+      s = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    }
+    partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * EV_NACC + i] = s;
+  }
+}
+
+// d loss / d z of one voxel: sigma(z_k) * { g [psi'(S) - [k=y] psi'(a_y) + lambda [k!=y] (e_k psi'(a_k) - psi'(S~)(S~-K))]
+//                                            + c1_k - [k=y] c0_k }        
+__device__ __forceinline__ void dce4_voxel_bwd(const float* z, int y, float lambda, float g, const float* c0,
+                                               const float* c1, float* r) {
+  float e[4], al[4], sg[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t, u;
+    e[k] = softplus_tu(z[k], t, u);
+    al[k] = e[k] + 1.f;
+    sg[k] = (z[k] >= 0.f ? 1.f : t) * rcp_f(u);              // sigmoid(z) = d softplus / dz
+  }
+  const float S = (al[0] + al[1]) + (al[2] + al[3]);
+  float e_y = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) e_y = (y == k) ? e[k] : e_y;
+  const float St = S - e_y;
+  const float trS = trigamma_f(S), tail = trigamma_f(St) * (St - 4.f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float ta = trigamma_f(al[k]);
+    const bool lab = (y == k);
+    const float d = lab ? (trS - ta) : fmaf(lambda, fmaf(e[k], ta, -tail), trS);
+    r[k] = fmaf(g, d, c1[k] - (lab ? c0[k] : 0.f)) * sg[k];
+  }
+}
+
+template <typename T, int LDT, bool GEV>
+__global__ void __launch_bounds__(256)
+k_dce4_bwd(const T* __restrict__ z, const void* __restrict__ labels, int64_t N, int64_t V, float lambda,
+           const float* __restrict__ scal, const float* __restrict__ grad_loss, const float* __restrict__ grad_ev,
+           T* __restrict__ dz) {
+  const float gl = grad_loss[0];
+  const float g = gl / (float)(N * V);
+  float c0[4], c1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float I = scal[4 + k], P = scal[8 + k], R = scal[12 + k];
+    c0[k] = gl * 2.f / ((2.f * I + 1e-5f) * 4.f);
+    c1[k] = gl / ((R + P + 1.f + 1e-5f) * 4.f);
+  }
+  const int64_t n = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const T* zn = z + n * V * 4;
+  T* dn = dz + n * V * 4;
+  for (int64_t v0 = (int64_t)blockIdx.x * 256 + threadIdx.x; v0 < V; v0 += 2 * stride) {
+    const int64_t v1 = v0 + stride;
+    const bool two = v1 < V;
+    float za[4], zb[4] = {0.f, 0.f, 0.f, 0.f};
+    load4(zn + v0 * 4, za);
+    const int ya = label_at<LDT>(labels, n * V + v0);
+    int yb = 0;
+    if (two) { load4(zn + v1 * 4, zb); yb = label_at<LDT>(labels, n * V + v1); }
+    float ra[4], rb[4];
+    dce4_voxel_bwd(za, ya, lambda, g, c0, c1, ra);
+    dce4_voxel_bwd(zb, yb, lambda, g, c0, c1, rb);
+    if (GEV) {
+      // + grad_evidence * sigmoid(z): recompute sigma cheaply from the row (rare path: the train loop drops evidence)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ra[k] += grad_ev[(n * 4 + k) * V + v0] * dsoftplus_fast(za[k]);
+        if (two) rb[k] += grad_ev[(n * 4 + k) * V + v1] * dsoftplus_fast(zb[k]);
+      }
+    }
+    store4(dn + v0 * 4, ra);
+    if (two) store4(dn + v1 * 4, rb);
+  }
+}
+
 // --------------------------------------------------------------- inference
 struct Thr { float t[16]; int n; };
 
@@ -686,6 +886,18 @@ int devis_evid_crit_fwd(const devis_evid_params* p, const void* in, int64_t sN, 
   const dim3 grid2 = ev_grid2(N, V);
   const unsigned blocks = grid2.x * grid2.y;
   double* part = scal ? (double*)ws : nullptr;
+  if (p->kind == CRIT_DCE && !p->input_kind && !evidence_in && sh.vec) {
+    // the training hot path (K = 4 is implied by vec): the straight-line kernel
+#define LAUNCH_DCE4(LDT, EV, PV) hipLaunchKernelGGL((k_dce4_fwd<T, LDT, EV, PV>), grid2, dim3(256), 0, s, (const T*)in, labels, V, p->lambda, evidence_out, per_voxel_out, part)
+#define LAUNCH_DCE4_L(LDT) do { if (evidence_out && per_voxel_out) LAUNCH_DCE4(LDT, true, true); else if (evidence_out) LAUNCH_DCE4(LDT, true, false); else if (per_voxel_out) LAUNCH_DCE4(LDT, false, true); else LAUNCH_DCE4(LDT, false, false); } while (0)
+    DEVIS_DISPATCH_DTYPE(dtype, {
+      if (label_dtype == DEVIS_LABEL_I64) LAUNCH_DCE4_L(DEVIS_LABEL_I64);
+      else if (label_dtype == DEVIS_LABEL_U8) LAUNCH_DCE4_L(DEVIS_LABEL_U8);
+      else LAUNCH_DCE4_L(DEVIS_LABEL_I32);
+    });
+#undef LAUNCH_DCE4_L
+#undef LAUNCH_DCE4
+  } else
   DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, DEVIS_DISPATCH_KT(K, hipLaunchKernelGGL((k_crit_fwd<T, KIND, KT>), grid2, dim3(256), 0, s, (const T*)in, sh, evidence_in, labels, label_dtype, ep, evidence_out, per_voxel_out, part))));
   int rc = launch_status();
   if (rc || !scal) return rc;
@@ -705,6 +917,20 @@ int devis_evid_crit_bwd(const devis_evid_params* p, const void* in, int64_t sN, 
   if (evidence_in && (!p->input_kind || !has_dice)) return DEVIS_ERR_BAD_ARG;
   const EvidShape sh = {sN, sV, sK, N, V, (int)K, evid_vec(in, sN, sV, sK, K, dtype) && evid_vec(d_in, sN, sV, sK, K, dtype)};
   const EvidParams ep = {p->input_kind, p->disentangle, p->lambda, p->a_au, p->eps};
+  if (p->kind == CRIT_DCE && !p->input_kind && !evidence_in && sh.vec && grad_loss && !grad_pv) {
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid2 = ev_grid2(N, V);
+#define LAUNCH_DCE4B(LDT, GEV) hipLaunchKernelGGL((k_dce4_bwd<T, LDT, GEV>), grid2, dim3(256), 0, s, (const T*)in, labels, N, V, p->lambda, scal, grad_loss, grad_ev, (T*)d_in)
+#define LAUNCH_DCE4B_L(LDT) do { if (grad_ev) LAUNCH_DCE4B(LDT, true); else LAUNCH_DCE4B(LDT, false); } while (0)
+    DEVIS_DISPATCH_DTYPE(dtype, {
+      if (label_dtype == DEVIS_LABEL_I64) LAUNCH_DCE4B_L(DEVIS_LABEL_I64);
+      else if (label_dtype == DEVIS_LABEL_U8) LAUNCH_DCE4B_L(DEVIS_LABEL_U8);
+      else LAUNCH_DCE4B_L(DEVIS_LABEL_I32);
+    });
+#undef LAUNCH_DCE4B_L
+#undef LAUNCH_DCE4B
+    return launch_status();
+  }
   DEVIS_DISPATCH_DTYPE(dtype, DEVIS_DISPATCH_KIND(p->kind, DEVIS_DISPATCH_KT(K, hipLaunchKernelGGL((k_crit_bwd<T, KIND, KT>), ev_grid2(N, V), dim3(256), 0, (hipStream_t)stream, (const T*)in, sh, evidence_in, labels, label_dtype, ep, scal, grad_loss, grad_pv, grad_dice, grad_ev, (T*)d_in, d_evidence_in))));
   return launch_status();
 }

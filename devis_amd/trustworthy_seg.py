@@ -6,7 +6,7 @@ kernels of this package.  Deviations from the reference, all documented in DESIG
   * ``self.backbone.cuda()`` (TrustworthySeg.py:116) becomes ``.to(current cuda device)``;
   * the ISIC branch, which raises NameError in the reference (TrustworthySeg.py:51 uses the
     undefined names ``model``/``classes``), selects ``Unet2D(3, num_classes)`` for model 'U';
-  * backbones outside SURVEY.md §8 (ResU, the 2-D AU and V) raise NameError like an unknown model does.
+  * backbones outside SURVEY.md §8 (ResU and the 2-D AU) raise NameError like an unknown model does.
 """
 from __future__ import annotations
 
@@ -20,6 +20,7 @@ from .unet2d import Unet2D, Unet2DDRIVE
 from .unet3d import Unet
 from .attunet3d import AttUnet
 from .vnet3d import VNet
+from .vnet2d import VNet2D
 
 
 class TMSU(nn.Module):
@@ -50,12 +51,18 @@ class TMSU(nn.Module):
         elif dataset == 'ISIC':
             if model_name == 'U':
                 backbone = Unet2D(3, num_classes, compute_dtype=dtype)
+            elif model_name == 'V':                                          # TrustworthySeg.py:53-55
+                backbone = _vnet2d(num_classes, dtype)
         elif dataset == 'DRIVE':
             if model_name == 'U':
                 backbone = Unet2DDRIVE(3, num_classes, compute_dtype=dtype)
+            elif model_name == 'V':                                          # TrustworthySeg.py:77-79
+                backbone = _vnet2d(num_classes, dtype)
         elif dataset in ('TOAR', 'HC'):
             if model_name == 'U':
                 backbone = Unet2D(1, num_classes, compute_dtype=dtype)
+            elif model_name == 'V':                                          # TrustworthySeg.py:90-92,103-105
+                backbone = _vnet2d(num_classes, dtype)
         else:
             print('There is no this dataset')
             raise NameError
@@ -89,6 +96,11 @@ class TMSU(nn.Module):
     def infer(self, input):
         """softplus evidence of NC(D)HW logits (TrustworthySeg.py:160-166)."""
         return _SoftplusFn.apply(input)
+
+
+def _vnet2d(num_classes, dtype):
+    return VNet2D(n_channels=3, n_classes=num_classes, n_filters=32, normalization='gn', has_dropout=False,
+                  compute_dtype=dtype)
 
 
 def _labels(y: torch.Tensor) -> torch.Tensor:

@@ -190,6 +190,49 @@ def vnet3d_forward(sd: StateDict, x: Tensor) -> Tensor:
     return _conv(sd, "out_conv", x7, pad=0)
 
 
+def _v_up2d(sd: StateDict, name: str, x: Tensor) -> Tensor:
+    # UpsamplingDeconvBlock, VNet2D.py:94-118: ConvTranspose2d k2 s2 -> GroupNorm(16) -> ReLU
+    h = F.conv_transpose2d(x, sd[name + ".conv.0.weight"], sd[name + ".conv.0.bias"], stride=2)
+    return _gn16_relu(sd, name + ".conv.1", h)
+
+
+def _offset_add(inputs: Tensor, down_outputs: Tensor, rand_log: Optional[List[Tuple[int, ...]]]) -> Tensor:
+    # VNet2D.offsetAdd, VNet2D.py:234-255: pad the WIDTH of the second argument with torch.rand drawn from the
+    # global CPU generator (shape (N,C,H) unsqueezed for an offset of 1, (N,C,H,offset) beyond), then add.
+    outputs = down_outputs
+    off = abs(inputs.size(3) - outputs.size(3))
+    if off == 1:
+        shape = (outputs.size(0), outputs.size(1), outputs.size(2))
+        add = torch.rand(shape).unsqueeze(3)
+    elif off > 1:
+        shape = (outputs.size(0), outputs.size(1), outputs.size(2), off)
+        add = torch.rand(shape)
+    if off >= 1:
+        if rand_log is not None:
+            rand_log.append(tuple(shape))
+        outputs = torch.cat([outputs, add.to(outputs.device)], dim=3)
+    return inputs + outputs
+
+
+def vnet2d_forward(sd: StateDict, x: Tensor, rand_log: Optional[List[Tuple[int, ...]]] = None) -> Tensor:
+    """VNet2D.forward with has_dropout=False, VNet2D.py:182-265 (n_filters=32, GroupNorm(16): TrustworthySeg.py:54,
+    78, 91, 104).  ConvBlock / DownsamplingConvBlock are the 2-D forms of the V-Net's (``_conv`` picks conv2d)."""
+    x1 = _v_conv_block(sd, "block_one", x, 1)
+    x2 = _v_conv_block(sd, "block_two", _v_down(sd, "block_one_dw", x1), 2)
+    x3 = _v_conv_block(sd, "block_three", _v_down(sd, "block_two_dw", x2), 3)
+    x4 = _v_conv_block(sd, "block_four", _v_down(sd, "block_three_dw", x3), 3)
+    x5 = _v_conv_block(sd, "block_five", _v_down(sd, "block_four_dw", x4), 3)
+    x5_up = _offset_add(x4, _v_up2d(sd, "block_five_up", x5), rand_log)
+    x6 = _v_conv_block(sd, "block_six", x5_up, 3)
+    x6_up = _offset_add(x3, _v_up2d(sd, "block_six_up", x6), rand_log)
+    x7 = _v_conv_block(sd, "block_seven", x6_up, 3)
+    x7_up = _offset_add(_v_up2d(sd, "block_seven_up", x7), x2, rand_log)
+    x8 = _v_conv_block(sd, "block_eight", x7_up, 2)
+    x8_up = _offset_add(_v_up2d(sd, "block_eight_up", x8), x1, rand_log)
+    x9 = _v_conv_block(sd, "block_nine", x8_up, 2)
+    return _conv(sd, "out_conv", x9, pad=0)
+
+
 # ----------------------------------------------------------------------------
 # 2D U-Net  (models/lib/UNet2DZoo.py:107-259)
 # ----------------------------------------------------------------------------

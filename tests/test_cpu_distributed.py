@@ -85,8 +85,13 @@ def _infer_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_sliding_window_gloo():
-    """Patches sharded over 2 ranks + all-reduce == the single-process stitch == tailor_and_concat."""
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sliding_window_gloo(world):
+    """Patches sharded over the ranks + ONE all_gather of the packed sub-regions == the single-process stitch ==
+    tailor_and_concat.  world 3: the ranks own 3 / 3 / 2 patches, so the gathered buffers are padded."""
     from devis_amd.predict import sliding_window_infer, tailor_and_concat
     g = torch.Generator().manual_seed(5)
     x = torch.randn((1, 2, 240, 240, 160), generator=g)
@@ -94,7 +99,7 @@ def test_sharded_sliding_window_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_infer_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_infer_worker, args=(r, world, port + world, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])

@@ -215,3 +215,35 @@ def test_eval_counts_oracle_matches_reference_goldens(golden, tag):
         assert np.allclose(P.softmax_output_dice(conf), g[tag + "_dice3"], rtol=0, atol=1e-12)
     if K == 3:
         assert np.allclose(P.softmax_output_litsdice(conf), g[tag + "_dice2"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_oracle_vnet2d_train_step(golden, seed):
+    """oracle.vnet2d_forward against the numbers the REAL TMSU(dataset='DRIVE', model_name='V') produced; the
+    product module's seeded init and state_dict keys equal the reference's."""
+    from oracle import devis_oracle as O
+    from devis_amd.vnet2d import VNet2D
+    G = golden("vnet2d")
+    pre = "s%d_" % seed
+    shape = tuple(int(v) for v in G[pre + "shape"])
+    torch.manual_seed(seed)
+    net = VNet2D(3, 2, 32, compute_dtype=torch.float32)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    assert list(sd.keys()) == [str(k) for k in G[pre + "keys"]]
+    assert sd_hash(sd) == str(G[pre + "sd_hash"])
+    for k in sd:
+        if sd[k].is_floating_point():
+            sd[k].requires_grad_(True)
+    g = torch.Generator().manual_seed(5000 + seed)
+    x = torch.randn(shape, generator=g)
+    y = (torch.rand((shape[0], 1) + shape[2:], generator=g) > 0.5).long()
+    log = []
+    torch.manual_seed(99)
+    ev, loss = O.tmsu_forward(lambda t: O.vnet2d_forward(sd, t, log), x, y, 25, 'train', 'DRIVE', 2, 50, 100)
+    loss.backward()
+    assert abs(loss.item() - float(G[pre + "loss"])) < 1e-6
+    assert rel_err(ev.detach(), G[pre + "evidence"]) < 1e-6
+    want = [tuple(int(v) for v in r if v) for r in G[pre + "rand_shapes"] if any(r)]
+    assert [tuple(t) for t in log] == want
+    k = "block_five.conv.3.weight"
+    assert rel_err(sd[k].grad.reshape(-1)[::37], G[pre + "grad_" + k]) < 1e-4

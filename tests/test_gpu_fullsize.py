@@ -6,6 +6,11 @@ import pytest
 import torch
 
 from tests.util import GRAD_L2_TOL, brats_args, l2_rel_err, rel_err
+from tests.util import BF16_BAR, FP32_BAR, LOSS_BF16_BAR, check
+
+# bf16 evidence, MAX-norm relative error over the 1 M sampled values at 2x4x128^3: north_star's 1e-2 where it is
+# met; exceptions (with the measured value) are listed per backbone
+BF16_EVIDENCE_MAX = {'AU': BF16_BAR, 'V': BF16_BAR}
 
 pytestmark = pytest.mark.gpu
 
@@ -34,17 +39,15 @@ def test_full_size_train_step_vs_oracle_live(model_name):
     ev_ref = ev_ref.detach()[..., ::4, ::4, ::4].clone()
     loss_ref = float(loss_ref.detach())
     del m
-    for dtype, ltol, etol, gtol, gatol in ((torch.float32, 1e-5 * abs(loss_ref) + 1e-6, 5e-5, GRAD_L2_TOL, 1e-5),
-                                           # bf16 evidence: L2 1e-2; the MAX over the 1 M sampled values is 2e-2 for
-                                           # the AttUnet as for the Unet, 3e-2 for the V-Net (measured 2.2e-2: its
-                                           # additive skips carry un-normalised bf16 sums through nine stages)
-                                           (torch.bfloat16, 1e-3, 3e-2 if model_name == 'V' else 2e-2, 0.08, 2e-3)):
+    for dtype, ltol, etol, gtol, gatol in ((torch.float32, FP32_BAR * abs(loss_ref), FP32_BAR, GRAD_L2_TOL, 1e-5),
+                                           (torch.bfloat16, LOSS_BF16_BAR, BF16_EVIDENCE_MAX[model_name], 0.08, 2e-3)):
         m = make(dtype)
         ev, loss = m(x.cuda(), y.cuda(), 25, 'train', 'BraTS')
         loss.backward()
-        assert abs(loss.item() - loss_ref) < ltol, (dtype, loss.item(), loss_ref)
-        assert rel_err(ev.detach()[..., ::4, ::4, ::4], ev_ref) < etol, dtype
-        assert l2_rel_err(ev.detach()[..., ::4, ::4, ::4], ev_ref) < (1e-2 if dtype == torch.bfloat16 else 2e-5), dtype
+        check(abs(loss.item() - loss_ref), ltol, "%s loss %s" % (model_name, dtype))
+        check(rel_err(ev.detach()[..., ::4, ::4, ::4], ev_ref), etol, "%s evidence %s" % (model_name, dtype))
+        check(l2_rel_err(ev.detach()[..., ::4, ::4, ::4], ev_ref), BF16_BAR if dtype == torch.bfloat16 else FP32_BAR,
+              "%s evidence L2 %s" % (model_name, dtype))
         params = dict(m.backbone.named_parameters())
         norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
         # biases in front of a norm layer have a zero true gradient (rounding noise on both sides): the absolute

@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.util import rel_err
+from tests.util import FP32_BAR, bf16_ulps, check, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -19,8 +19,20 @@ def uncl(t):                        # channels-last GPU -> NC... cpu fp32
     return t.float().permute(*perm).contiguous().cpu()
 
 
-def tol(dtype):
-    return 2e-5 if dtype == torch.float32 else 2e-2
+def close(y, ref, dtype, what):
+    """A kernel OUTPUT TENSOR in the compute dtype.  fp32 mode: 1e-5 of the largest reference value.  bf16 mode:
+    the kernels accumulate in fp32 and round once, so every element must be the reference (fp32 on the same
+    rounded operands) rounded to bf16, or its neighbour: <= 1 bf16 ulp."""
+    if dtype == torch.float32:
+        check(rel_err(y, ref), FP32_BAR, what)
+    else:
+        check(bf16_ulps(y, ref), 1.0, what + " [bf16 ulps]")
+
+
+def close32(y, ref, dtype, what):
+    """An fp32 OUTPUT (weight / bias gradient, statistics) of a kernel: 1e-5 in fp32 mode; in bf16 mode the operands
+    are bf16 but the sums are fp32 (fp64 for statistics), so 1e-4 - four orders tighter than a bf16 rounding."""
+    check(rel_err(y, ref), FP32_BAR if dtype == torch.float32 else 1e-4, what)
 
 
 CONV_CASES = [
@@ -93,6 +105,8 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, prologue):
     if prologue:
         shape = (n, c1 + c2) + (1,) * nd
         a = F.relu(xr * sc.view(shape) + sh.view(shape))
+        if dtype == torch.bfloat16:      # the prologue's result is the bf16 MFMA operand
+            a = a.bfloat16().float()
     yr = conv(a, wr, br, stride=s, padding=p)
     res = torch.randn(yr.shape, generator=g)
     if dtype == torch.bfloat16:
@@ -109,21 +123,21 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, prologue):
     wp = ops.pack_conv_weight(w.cuda(), dtype)
     scg, shg = (sc.cuda().contiguous(), sh.cuda().contiguous()) if prologue else (None, None)
     y = ops.conv_fwd(x1, x2, wp, b.cuda(), geom, scg, shg, residual=cl(res, dtype))
-    assert rel_err(uncl(y), (yr + res).detach()) < tol(dtype)
+    close(uncl(y), (yr + res).detach(), dtype, "y")
     dx1, dx2 = ops.conv_dgrad(cl(dy, dtype), wp, geom, x1.shape, c2)
     da = a.grad
-    assert rel_err(uncl(dx1), da[:, :c1]) < tol(dtype)
+    close(uncl(dx1), da[:, :c1], dtype, "dx1")
     if c2:
-        assert rel_err(uncl(dx2), da[:, c1:]) < tol(dtype)
+        close(uncl(dx2), da[:, c1:], dtype, "dx2")
     dw, db = ops.conv_wgrad(x1, x2, cl(dy, dtype), geom, w.shape, scg, shg)
-    assert rel_err(dw, wr.grad) < tol(dtype)
-    assert rel_err(db, br.grad) < tol(dtype)
+    close32(dw, wr.grad, dtype, "dw")
+    close32(db, br.grad, dtype, "db")
     if k == (2, 2, 2):            # the skip gradient the V-Net adds in this dgrad's epilogue
         rs = torch.randn(x[:, :c1].shape, generator=g)
         if dtype == torch.bfloat16:
             rs = rs.bfloat16().float()
         dxr, _ = ops.conv_dgrad(cl(dy, dtype), wp, geom, x1.shape, c2, residual=cl(rs, dtype))
-        assert rel_err(uncl(dxr), da[:, :c1] + rs) < tol(dtype)
+        close(uncl(dxr), da[:, :c1] + rs, dtype, "dx+skip")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -150,12 +164,12 @@ def test_convT(case, dtype):
     wp = ops.pack_convT_weight(w.cuda(), dtype)
     xg = cl(x, dtype)
     y = ops.convT_fwd(xg, wp, b.cuda(), k)
-    assert rel_err(uncl(y), yr.detach()) < tol(dtype)
+    close(uncl(y), yr.detach(), dtype, "y")
     dx = ops.convT_dgrad(cl(dy, dtype), wp, k, xg.shape)
-    assert rel_err(uncl(dx), xr.grad) < tol(dtype)
+    close(uncl(dx), xr.grad, dtype, "dx")
     dw, db = ops.convT_wgrad(xg, cl(dy, dtype), k, w.shape)
-    assert rel_err(dw, wr.grad) < tol(dtype)
-    assert rel_err(db, br.grad) < tol(dtype)
+    close32(dw, wr.grad, dtype, "dw")
+    close32(db, br.grad, dtype, "db")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -197,12 +211,11 @@ def test_norm_relu_fwd_bwd(shape, kind, dtype):
         groups, bn = 0, True
         assert rel_err(rmg, rm) < 1e-5 and rel_err(rvg, rv) < 1e-5
     y = ops.affine_act(xg, sc, sh, relu=True)
-    assert rel_err(uncl(y), yr.detach()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    close(uncl(y), yr.detach(), dtype, "y")
     dx, dgm, dbt = ops.norm_relu_bwd(cl(dy, dtype), xg, sc, sh, gg, mean, rstd, groups, bn, extra=cl(extra, dtype))
-    t = 2e-5 if dtype == torch.float32 else 2e-2
-    assert rel_err(uncl(dx), dxr) < t
-    assert rel_err(dgm, gr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
-    assert rel_err(dbt, br.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    close(uncl(dx), dxr, dtype, "dx")
+    close32(dgm, gr.grad, dtype, "dgamma")
+    close32(dbt, br.grad, dtype, "dbeta")
 
 
 def test_bn_eval_mode():
@@ -419,5 +432,6 @@ def test_conv_epilogue_backward_moments(case):
     mean, rstd = torch.randn((n, 8), generator=g).cuda() * 0.1, torch.rand((n, 8), generator=g).cuda() + 0.5
     a = ops.norm_relu_bwd(dx, xref, sc, sh, gamma, mean, rstd, 8, False, partials=part)
     r = ops.norm_relu_bwd(dx, xref, sc, sh, gamma, mean, rstd, 8, False)
-    for u, v in zip(a, r):
-        assert rel_err(u, v) < 2e-2      # dx is bf16; the coefficients agree far tighter (checked above)
+    close(a[0].float().cpu(), r[0].float().cpu(), torch.bfloat16, "dx via epilogue moments vs separate pass")
+    close32(a[1], r[1], torch.bfloat16, "dgamma")
+    close32(a[2], r[2], torch.bfloat16, "dbeta")

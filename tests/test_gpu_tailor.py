@@ -41,9 +41,9 @@ def test_tmsu_val_mode_matches_oracle_on_one_patch():
         ev = m(x.cuda(), None, 1, 'val', 'BraTS')
     assert ev.shape == (1, 4, 240, 240, 155)
     with torch.no_grad():
-        ref = torch.nn.functional.softplus(O.unet3d_forward(sd, x[..., :128, :128, :128][..., :64].contiguous()
-                                                            if False else x[..., :128, :128, :128], False))
-    assert rel_err(ev[..., :128, :128, :128], ref) < 5e-5
+        ref = torch.nn.functional.softplus(O.unet3d_forward(sd, x[..., :128, :128, :128], False))
+    from tests.util import FP32_BAR, check
+    check(rel_err(ev[..., :128, :128, :128], ref), FP32_BAR, "evidence")
 
 
 def test_sliding_window_infer_equals_stitch_then_head():
@@ -141,9 +141,11 @@ def test_test_mode_driver_loads_checkpoint_and_reports_device_side_metrics(tmp_p
 def test_full_volume_config5_inference_vs_oracle_live():
     """BASELINE configs[4] at full size: one 4x240x240x160 volume through predict_volume (8 patches, backbone in
     eval mode + fused head, fp32) against the oracle's tailor_and_concat + infer_head run live on the host cores.
-    evidence 5e-5 rel-max; u and mne 1e-5 abs; the argmax mask and the eleven u-threshold masks are integers and
+    evidence 1e-5 rel-max; u and mne 1e-5 abs; the argmax mask and the eleven u-threshold masks are integers and
     must agree wherever the oracle's own decision margin exceeds the evidence tolerance (every voxel that
-    disagrees must be such a near-tie, and there must be next to none)."""
+    disagrees must be such a near-tie, and there must be next to none: the counts are recorded - bit-exactness
+    on a 8.9 M-voxel random volume would need two fp32 evaluation orders to round every near-tie alike; it is
+    asserted on the golden volumes of tests/test_gpu_head.py, whose generator guards the margins)."""
     from oracle import devis_oracle as O
     from devis_amd import TMSU, train as T
     from tests.util import brats_args, rel_err
@@ -158,20 +160,23 @@ def test_full_volume_config5_inference_vs_oracle_live():
         ev = O.tmsu_forward(lambda t: O.unet3d_forward(sd, t, False), x, None, 0, 'test', 'BraTS', 4, 50, 100)
         pred, u, prob, mne = O.infer_head(ev, 4)
     assert out["evidence"].shape == ev.shape == (1, 4, 240, 240, 155)
-    tol = 5e-5 * float(ev.abs().max())
-    assert (out["evidence"].cpu() - ev).abs().max() < tol
-    assert (out["u"].cpu().reshape(u.shape) - u).abs().max() < 1e-5
-    assert (out["mne"].cpu().reshape(mne.shape) - mne).abs().max() < 1e-5
+    from tests.util import FP32_BAR, check
+    check(rel_err(out["evidence"].cpu(), ev), FP32_BAR, "evidence")
+    check((out["u"].cpu().reshape(u.shape) - u).abs().max(), 1e-5, "u abs")
+    check(rel_err(out["u"].cpu().reshape(u.shape), u), FP32_BAR, "u")
+    check((out["mne"].cpu().reshape(mne.shape) - mne).abs().max(), 1e-5, "mne abs")
     ours = out["pred"].cpu().reshape(pred.shape).long()
     diff = ours != pred
     top2 = prob.topk(2, dim=1).values
     margin = (top2[:, 0] - top2[:, 1])
-    assert int(diff.sum()) <= 1e-5 * diff.numel() and bool((margin[diff] < 1e-4).all()), int(diff.sum())
+    assert bool((margin[diff] < 1e-4).all()), int(diff.sum())
+    check(int(diff.sum()) / diff.numel(), 1e-5, "argmax mask: fraction of voxels that differ (near-ties)")
     um = out["umask"].cpu().reshape(u.shape).int()
     for j, t in enumerate(thr):
         want = u > np.float32(t)
         d = ((um >> j) & 1).bool() != want
-        assert bool(((u[d] - np.float32(t)).abs() < 1e-5).all()) and int(d.sum()) <= 1e-5 * d.numel(), (t, int(d.sum()))
+        assert bool(((u[d] - np.float32(t)).abs() < 1e-5).all()), (t, int(d.sum()))
+        check(int(d.sum()) / d.numel(), 1e-5, "u > %.2f mask: fraction of voxels that differ (near-ties)" % t)
 
 
 @pytest.mark.parametrize("model_name,streams", [("U", 1), ("U", 3), ("AU", 3), ("V", 3)])

@@ -3,7 +3,7 @@ including the torch.rand skip padding drawn from the global CPU generator (UNet2
 import pytest
 import torch
 
-from tests.util import GRAD_L2_TOL, GRAD_MAX_TOL, l2_rel_err, rel_err, sd_hash
+from tests.util import BF16_BAR, FP32_BAR, GRAD_L2_TOL, GRAD_MAX_TOL, LOSS_BF16_BAR, check, l2_rel_err, rel_err, sd_hash
 
 pytestmark = pytest.mark.gpu
 
@@ -29,8 +29,8 @@ def test_unet2d_fp32_vs_golden(golden, tag, drive, cin):
     _, loss = evidential_head_loss(logits_cl, y.cuda(), 25, 50, channels_last=True, want_evidence=False)
     loss.backward()
     logits = logits_cl.detach().permute(0, 3, 1, 2)
-    assert rel_err(logits, G[tag + "_logits"]) < 5e-5
-    assert abs(loss.item() - float(G[tag + "_loss"])) < 1e-5
+    check(rel_err(logits, G[tag + "_logits"]), FP32_BAR, "logits")
+    check(abs(loss.item() - float(G[tag + "_loss"])) / abs(float(G[tag + "_loss"])), FP32_BAR, "loss")
     params = dict(net.named_parameters())
     for k in GRADS:
         # 2-D golden images are tiny (conv5 normalises over 16-32 values) and add MaxPool argmax gates to the ReLU
@@ -48,28 +48,51 @@ def test_unet2d_bf16(golden):
     g = torch.Generator().manual_seed(2000)
     x = torch.randn(shape, generator=g)
     logits = net(x.cuda())
-    assert rel_err(logits, G[tag + "_logits"]) < 3e-2
+    check(rel_err(logits, G[tag + "_logits"]), BF16_BAR, "logits")
 
 
-def test_isic_plumbing_shape():
-    """configs[0]: ISIC-shaped 3x224x300, K=2 - the rand padding fires at merge6 and merge7."""
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_isic_config0_vs_oracle_live(dtype):
+    """BASELINE configs[0] at its full size: ISIC-shaped 1x3x224x300, K=2, TMSU forward + evidential loss (and the
+    backward), against the CPU oracle run live on the same tensors.  W = 300 is not divisible by 16, so the
+    torch.rand skip padding fires at merge6 and merge7 (UNet2DZoo.py:162-182): both sides draw it from the global
+    CPU generator seeded alike."""
+    import numpy as np
+    from oracle import devis_oracle as O
     from devis_amd import TMSU
     from tests.util import brats_args
     torch.manual_seed(0)
-    m = TMSU(brats_args(dataset='ISIC', num_classes=2, compute_dtype=torch.float32)).train()
+    m = TMSU(brats_args(dataset='ISIC', num_classes=2, compute_dtype=dtype)).train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.backbone.state_dict().items()}
+    names = [k for k, _ in m.backbone.named_parameters()]
     g = torch.Generator().manual_seed(1)
-    x = torch.randn((1, 3, 224, 300), generator=g).cuda()
-    y = (torch.rand((1, 1, 224, 300), generator=g) > 0.5).long().cuda()
-    ev, loss = m(x, y, 25, 'train', 'ISIC')
+    x = torch.randn((1, 3, 224, 300), generator=g)
+    y = (torch.rand((1, 1, 224, 300), generator=g) > 0.5).long()
+    torch.manual_seed(99)
+    ev, loss = m(x.cuda(), y.cuda(), 25, 'train', 'ISIC')
     loss.backward()
     assert ev.shape == (1, 2, 224, 300) and torch.isfinite(loss)
+    for k in names:
+        sd[k].requires_grad_(True)
+    torch.manual_seed(99)
+    ev_ref, loss_ref = O.tmsu_forward(lambda t: O.unet2d_forward(sd, t, True), x, y, 25, 'train', 'ISIC', 2, 50, 100)
+    loss_ref.backward()
+    fp32 = dtype == torch.float32
+    check(abs(loss.item() - loss_ref.item()) / (abs(loss_ref.item()) if fp32 else 1.0), FP32_BAR if fp32 else LOSS_BF16_BAR,
+          "loss")
+    check(rel_err(ev.detach(), ev_ref.detach()), FP32_BAR if fp32 else BF16_BAR, "evidence")
+    params = dict(m.backbone.named_parameters())
+    norms = np.array([params[k].grad.double().norm().item() for k in sorted(names)])
+    ref = np.array([sd[k].grad.double().norm().item() for k in sorted(names)])
+    gtol, gatol = (GRAD_L2_TOL, 1e-6) if fp32 else (0.08, 1e-3)
+    check(np.max((np.abs(norms - ref) - gatol * ref.max()) / (ref + 1e-30)), gtol, "grad norms")
 
 
 def test_full_size_config2_train_step_vs_oracle_live():
     """BASELINE configs[1] at its full size (Unet2D(1,2), batch 16 of 1x256x256, epoch 25): loss, logits and every
     parameter's gradient norm of one train step against the CPU oracle run live on the same seeded tensors.
-    fp32: loss 1e-5 rel, logits 5e-5 rel-max, gradient norms GRAD_L2_TOL; bf16: loss 1e-3 abs, logits 3e-2,
-    gradient norms 8 %."""
+    fp32: loss 1e-5 rel, logits 1e-5 rel-max, gradient norms GRAD_L2_TOL; bf16: loss 1e-3 abs, logits 1e-2,
+    gradient norms 8 % (north_star's bars; measured values are recorded)."""
     import numpy as np
     from oracle import devis_oracle as O
     from devis_amd import Unet2D
@@ -91,17 +114,16 @@ def test_full_size_config2_train_step_vs_oracle_live():
     ref = np.array([sd[k].grad.double().norm().item() for k in sorted(names)])
     lref = logits_ref[0].detach()
     loss_ref = float(loss_ref.detach())
-    for dtype, ltol, ztol, gtol, gatol in ((torch.float32, 1e-5 * abs(loss_ref) + 1e-6, 5e-5, GRAD_L2_TOL, 1e-6),
-                                           (torch.bfloat16, 1e-3, 3e-2, 0.08, 1e-3)):
+    for dtype, ltol, ztol, gtol, gatol in ((torch.float32, FP32_BAR * abs(loss_ref), FP32_BAR, GRAD_L2_TOL, 1e-6),
+                                           (torch.bfloat16, LOSS_BF16_BAR, BF16_BAR, 0.08, 1e-3)):
         torch.manual_seed(4)
         net = Unet2D(1, 2, compute_dtype=dtype).cuda().train()
         logits_cl = net.forward_channels_last(x.cuda())
         _, loss = evidential_head_loss(logits_cl, y.cuda(), 25, 50, channels_last=True, want_evidence=False)
         loss.backward()
-        assert abs(loss.item() - loss_ref) < ltol, (dtype, loss.item(), loss_ref)
-        assert rel_err(logits_cl.detach().permute(0, 3, 1, 2).float(), lref) < ztol, dtype
+        check(abs(loss.item() - loss_ref), ltol, "loss %s" % dtype)
+        check(rel_err(logits_cl.detach().permute(0, 3, 1, 2).float(), lref), ztol, "logits %s" % dtype)
         params = dict(net.named_parameters())
         assert sorted(params) == sorted(names)
         norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
-        assert np.all(np.abs(norms - ref) <= gtol * ref + gatol * ref.max()), \
-            (dtype, np.max(np.abs(norms - ref) / (ref + 1e-30)))
+        check(np.max((np.abs(norms - ref) - gatol * ref.max()) / (ref + 1e-30)), gtol, "grad norms %s" % dtype)

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import GRAD_L2_TOL, GRAD_MAX_TOL, brats_args, l2_rel_err, rel_err, sd_hash
+from tests.util import (BF16_BAR, FP32_BAR, GRAD_L2_TOL, GRAD_MAX_TOL, LOSS_BF16_BAR, brats_args, check, l2_rel_err,
+                        rel_err, sd_hash)
 
 pytestmark = pytest.mark.gpu
 
@@ -43,9 +44,9 @@ def test_train_step_fp32_vs_golden(golden, seed, epoch):
     ev, loss = m(x.cuda(), y.cuda(), epoch, 'train', 'BraTS')
     loss.requires_grad_(True).backward()
     torch.cuda.synchronize()
-    assert abs(loss.item() - float(G[pre + "loss"])) < 1e-5 * abs(float(G[pre + "loss"])) + 1e-6
+    check(abs(loss.item() - float(G[pre + "loss"])) / abs(float(G[pre + "loss"])), FP32_BAR, "loss")
     if pre + "evidence" in G.files:
-        assert rel_err(ev.detach()[..., ::2], G[pre + "evidence"]) < 2e-5     # logits/alpha: 1e-5-class in fp32
+        check(rel_err(ev.detach()[..., ::2], G[pre + "evidence"]), FP32_BAR, "evidence")   # north_star: 1e-5 in fp32
     params = dict(m.backbone.named_parameters())
     for k in WATCH:
         g = params[k].grad
@@ -64,7 +65,7 @@ def test_train_step_fp32_vs_golden(golden, seed, epoch):
         m.eval()
         with torch.no_grad():
             lg = m.backbone(x.cuda())
-        assert rel_err(lg[..., ::2], G[pre + "eval_logits"]) < 2e-5
+        check(rel_err(lg[..., ::2], G[pre + "eval_logits"]), FP32_BAR, "eval_logits")
 
 
 def test_train_step_bf16_vs_golden(golden):
@@ -75,8 +76,11 @@ def test_train_step_bf16_vs_golden(golden):
     x, y = _inputs(0, shape)
     ev, loss = m(x.cuda(), y.cuda(), 25, 'train', 'BraTS')
     loss.backward()
-    assert abs(loss.item() - float(G[pre + "loss"])) < 1e-3                     # north_star: loss within 1e-3
-    assert rel_err(ev.detach()[..., ::2], G[pre + "evidence"]) < 2e-2          # alpha within 1e-2-class
+    check(abs(loss.item() - float(G[pre + "loss"])), LOSS_BF16_BAR, "loss")     # north_star: loss within 1e-3
+    check(rel_err(ev.detach()[..., ::2], G[pre + "evidence"]), BF16_BAR, "evidence")   # north_star: 1e-2 in bf16
+    alpha_ref = torch.from_numpy(G[pre + "evidence"]) + 1
+    check(rel_err(ev.detach()[..., ::2].cpu() + 1, alpha_ref), BF16_BAR, "alpha")
+    check(rel_err(4.0 / (ev.detach()[..., ::2].cpu() + 1).sum(1), 4.0 / alpha_ref.sum(1)), BF16_BAR, "u")
     params = dict(m.backbone.named_parameters())
     norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
     ref = G[pre + "gradnorm_all"]
@@ -95,7 +99,7 @@ def test_backbone_matches_oracle_live():
     x = torch.randn((2, 4, 8, 24, 16), generator=g)
     out = net(x.cuda())
     ref = O.unet3d_forward(sd, x, True)
-    assert rel_err(out.detach(), ref) < 2e-5
+    check(rel_err(out.detach(), ref), FP32_BAR, "logits")
     for k in ("DeBlock3.bn1.running_var", "DeBlock2.bn2.running_mean"):
         assert rel_err(net.state_dict()[k], sd[k]) < 1e-5
 
@@ -181,8 +185,8 @@ def test_backward_reproducibility_one_and_two_streams(monkeypatch):
 def test_full_size_config3_train_step_vs_oracle_live():
     """BASELINE configs[2] at its full size (B=2, 4x128^3, K=4, epoch 25): loss, evidence and every parameter's
     gradient norm of ONE train step against the CPU oracle run live on the same seeded tensors (a few seconds on
-    the box's host cores).  fp32: loss 1e-5 rel, evidence 5e-5 rel-max, gradient norms GRAD_L2_TOL;
-    bf16: loss 1e-3 abs, evidence 2e-2, gradient norms 8 % (the bars of the small golden cases)."""
+    the box's host cores).  fp32: loss 1e-5 rel, evidence 1e-5 rel-max, gradient norms GRAD_L2_TOL;
+    bf16: loss 1e-3 abs, evidence 1e-2, gradient norms 8 % (north_star's bars; measured values are recorded)."""
     from oracle import devis_oracle as O
     shape = (2, 4, 128, 128, 128)
     x, y = _inputs(11, shape)
@@ -196,16 +200,16 @@ def test_full_size_config3_train_step_vs_oracle_live():
     ref = np.array([sd[k].grad.double().norm().item() for k in sorted(names)])
     ev_ref = ev_ref.detach()[..., ::4, ::4, ::4].clone()
     loss_ref = float(loss_ref.detach())
-    for dtype, ltol, etol, gtol, gatol in ((torch.float32, 1e-5 * abs(loss_ref) + 1e-6, 5e-5, GRAD_L2_TOL, 1e-6),
-                                           (torch.bfloat16, 1e-3, 2e-2, 0.08, 1e-3)):
+    for dtype, ltol, etol, gtol, gatol in ((torch.float32, FP32_BAR * abs(loss_ref), FP32_BAR, GRAD_L2_TOL, 1e-6),
+                                           (torch.bfloat16, LOSS_BF16_BAR, BF16_BAR, 0.08, 1e-3)):
         m = _make(11, dtype)
         ev, loss = m(x.cuda(), y.cuda(), 25, 'train', 'BraTS')
         loss.backward()
-        assert abs(loss.item() - loss_ref) < ltol, (dtype, loss.item(), loss_ref)
-        assert rel_err(ev.detach()[..., ::4, ::4, ::4], ev_ref) < etol, dtype
+        check(abs(loss.item() - loss_ref), ltol, "loss %s" % dtype)
+        check(rel_err(ev.detach()[..., ::4, ::4, ::4], ev_ref), etol, "evidence %s" % dtype)
+        check(l2_rel_err(ev.detach()[..., ::4, ::4, ::4], ev_ref), etol, "evidence L2 %s" % dtype)
         params = dict(m.backbone.named_parameters())
         norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
-        assert np.all(np.abs(norms - ref) <= gtol * ref + gatol * ref.max()), \
-            (dtype, np.max(np.abs(norms - ref) / (ref + 1e-30)))
+        check(np.max((np.abs(norms - ref) - gatol * ref.max()) / (ref + 1e-30)), gtol, "grad norms %s" % dtype)
         del m, ev, loss, params
         torch.cuda.empty_cache()
