@@ -381,10 +381,15 @@ k_evid_finalize(const double* __restrict__ partial, int blocks, int K, double NV
 #pragma unroll
   for (int i = 0; i < EV_NACC; ++i) a[i] = 0.0;
   for (int b = t; b < blocks; b += 1024) {
+    // every slot of a row is written by the forward kernels (zeros for classes >= K): load all 25 without a
+    // predicate, so the loads are issued together and one memory latency covers them
     const double* row = partial + (int64_t)b * EV_NACC;
+    double v[EV_NACC];
 #pragma unroll
-    for (int i = 0; i < EV_NACC; ++i)
-      if (i == 0 || (i - 1) % EV_MAXK < K) a[i] += row[i];
+    for (int i = 0; i < EV_NACC; ++i) v[i] = row[i];
+    __builtin_amdgcn_sched_barrier(0);      // all loads in flight before the first add waits (else: 13 latencies in series)
+#pragma unroll
+    for (int i = 0; i < EV_NACC; ++i) a[i] += v[i];
   }
 #pragma unroll
   for (int i = 0; i < EV_NACC; ++i) {

@@ -34,8 +34,11 @@ def pytest_sessionfinish(session, exitstatus):
     try:
         os.makedirs(out_dir, exist_ok=True)
         import json
-        rows = {k: {"measured_max": max(v[0] for v in vs), "bar": vs[0][1], "n": len(vs)}
-                for k, vs in sorted(util.PARITY_LOG.items())}
+        rows = {}
+        for k, vs in sorted(util.PARITY_LOG.items()):
+            worst = max(vs, key=lambda v: v[0] / v[1] if v[1] > 0 else v[0])       # closest to (or furthest over) its bar
+            rows[k] = {"measured_max": max(v[0] for v in vs), "worst_vs_bar": worst[0], "bar": worst[1], "n": len(vs),
+                       "worst_case": worst[2], "over": [[v[2], v[0], v[1]] for v in vs if v[0] > v[1]][:40]}
         with open(os.path.join(out_dir, "parity_measured.json"), "w") as f:
             json.dump(rows, f, indent=1)
     except OSError:

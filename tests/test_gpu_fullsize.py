@@ -6,11 +6,11 @@ import pytest
 import torch
 
 from tests.util import GRAD_L2_TOL, brats_args, l2_rel_err, rel_err
-from tests.util import BF16_BAR, FP32_BAR, LOSS_BF16_BAR, check
+from tests.util import BF16_BAR, BF16_MAX_EXCEPTION, FP32_BAR, LOSS_BF16_BAR, check
 
 # bf16 evidence, MAX-norm relative error over the 1 M sampled values at 2x4x128^3: north_star's 1e-2 where it is
 # met; exceptions (with the measured value) are listed per backbone
-BF16_EVIDENCE_MAX = {'AU': BF16_BAR, 'V': BF16_BAR}
+BF16_EVIDENCE_MAX = dict(BF16_MAX_EXCEPTION)
 
 pytestmark = pytest.mark.gpu
 

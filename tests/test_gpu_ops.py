@@ -98,24 +98,38 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, prologue):
     if dtype == torch.bfloat16:      # compare on the rounded operands
         x, w = x.bfloat16().float(), w.bfloat16().float()
     conv = F.conv3d if nd == 3 else F.conv2d
-    xr = x.clone().requires_grad_(True)
-    wr = w.clone().requires_grad_(True)
-    br = b.clone().requires_grad_(True)
-    a = xr
-    if prologue:
-        shape = (n, c1 + c2) + (1,) * nd
-        a = F.relu(xr * sc.view(shape) + sh.view(shape))
-        if dtype == torch.bfloat16:      # the prologue's result is the bf16 MFMA operand
-            a = a.bfloat16().float()
-    yr = conv(a, wr, br, stride=s, padding=p)
-    res = torch.randn(yr.shape, generator=g)
-    if dtype == torch.bfloat16:
-        res = res.bfloat16().float()
-    dy = torch.randn(yr.shape, generator=g)
-    if dtype == torch.bfloat16:
-        dy = dy.bfloat16().float()
-    a.retain_grad()
-    (yr + res).backward(dy)
+    res = dy = None
+
+    def reference(round_a):
+        """torch fp32 on the same (bf16-rounded) operands -> (y + res, d/d(post-prologue input), dw, db)"""
+        nonlocal res, dy
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True)
+        a = xr
+        if prologue:
+            shape = (n, c1 + c2) + (1,) * nd
+            # the kernels' prologue is ONE fused multiply-add in fp32 (product exact in fp64, one rounding)
+            a = F.relu((xr.double() * sc.view(shape).double() + sh.view(shape).double()).float())
+            if round_a:
+                a = a.bfloat16().float()
+        yr = conv(a, wr, br, stride=s, padding=p)
+        if res is None:
+            res = torch.randn(yr.shape, generator=g)
+            dy = torch.randn(yr.shape, generator=g)
+            if dtype == torch.bfloat16:
+                res, dy = res.bfloat16().float(), dy.bfloat16().float()
+        a.retain_grad()
+        (yr + res).backward(dy)
+        return (yr + res).detach(), a.grad, wr.grad, br.grad
+
+    # bf16 + prologue: the MFMA kernels round relu(scale * x + shift) to bf16 (it is their matrix operand); the
+    # generic kernels, which take the (shape, prologue) pairs no network uses, keep it in fp32.  Either is a correct
+    # evaluation; forward and weight gradient are separate C-ABI calls (possibly of different kernel families), so
+    # each of the two outputs the prologue enters (y, dw) is held to the closer ONE of the two references.
+    refs = [reference(False)]
+    if prologue and dtype == torch.bfloat16:
+        refs.append(reference(True))
 
     geom = ops.ConvGeom(k, s, p)
     x1 = cl(x[:, :c1], dtype)
@@ -123,15 +137,17 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, prologue):
     wp = ops.pack_conv_weight(w.cuda(), dtype)
     scg, shg = (sc.cuda().contiguous(), sh.cuda().contiguous()) if prologue else (None, None)
     y = ops.conv_fwd(x1, x2, wp, b.cuda(), geom, scg, shg, residual=cl(res, dtype))
-    close(uncl(y), (yr + res).detach(), dtype, "y")
+    measure = (lambda r: bf16_ulps(uncl(y), r[0])) if dtype == torch.bfloat16 else (lambda r: rel_err(uncl(y), r[0]))
+    yref, da, _, db_ref = min(refs, key=measure)
+    close(uncl(y), yref, dtype, "y")
     dx1, dx2 = ops.conv_dgrad(cl(dy, dtype), wp, geom, x1.shape, c2)
-    da = a.grad
     close(uncl(dx1), da[:, :c1], dtype, "dx1")
     if c2:
         close(uncl(dx2), da[:, c1:], dtype, "dx2")
     dw, db = ops.conv_wgrad(x1, x2, cl(dy, dtype), geom, w.shape, scg, shg)
-    close32(dw, wr.grad, dtype, "dw")
-    close32(db, br.grad, dtype, "db")
+    dw_ref = min((r[2] for r in refs), key=lambda r: rel_err(dw, r))
+    close32(dw, dw_ref, dtype, "dw")
+    close32(db, db_ref, dtype, "db")
     if k == (2, 2, 2):            # the skip gradient the V-Net adds in this dgrad's epilogue
         rs = torch.randn(x[:, :c1].shape, generator=g)
         if dtype == torch.bfloat16:
