@@ -111,14 +111,15 @@ k_pw_mfma(PwArgs a) {
   bool ok[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int64_t tile = (((int64_t)blockIdx.x * iters + it) * 4 + wave) * NT + j;
-    const bool tv = tile < a.ntiles;
-    const int64_t tt = tv ? tile : 0;
-    const int twi = (int)(tt % a.ntw);
-    int64_t r = tt / a.ntw;
-    hh[j] = (int)(r % a.H); r /= a.H;
-    dd[j] = (int)(r % a.D);
-    nn[j] = (int)(r / a.D);
+    // 32-bit index arithmetic (hosts check voxels < 2^31): 64-bit divisions cost ~100 VALU instructions each
+    const unsigned tile = (((unsigned)blockIdx.x * (unsigned)iters + (unsigned)it) * 4u + (unsigned)wave) * NT + j;
+    const bool tv = tile < (unsigned)a.ntiles;
+    const unsigned tt = tv ? tile : 0u;
+    const int twi = (int)(tt % (unsigned)a.ntw);
+    unsigned r = tt / (unsigned)a.ntw;
+    hh[j] = (int)(r % (unsigned)a.H); r /= (unsigned)a.H;
+    dd[j] = (int)(r % (unsigned)a.D);
+    nn[j] = (int)(r / (unsigned)a.D);
     ww[j] = twi * 16 + l15;
     ok[j] = tv && ww[j] < a.W;
   }

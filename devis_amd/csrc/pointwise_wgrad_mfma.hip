@@ -96,11 +96,11 @@ k_pw_wgrad(PwWgArgs a) {
           if (c < a.C1) val = load_piece(a.n1 + gv * a.C1, c, a.C1);
           else val = load_piece(a.n2 + gv * a.C2, c - a.C1, a.C2);
         } else {
-          int64_t r = gv;
-          const int w = (int)(r % a.W); r /= a.W;
-          const int h = (int)(r % a.H); r /= a.H;
-          const int d = (int)(r % a.D);
-          const int n = (int)(r / a.D);
+          unsigned r = (unsigned)gv;          // voxel counts are < 2^31 (host check): no 64-bit divisions
+          const int w = (int)(r % (unsigned)a.W); r /= (unsigned)a.W;
+          const int h = (int)(r % (unsigned)a.H); r /= (unsigned)a.H;
+          const int d = (int)(r % (unsigned)a.D);
+          const int n = (int)(r / (unsigned)a.D);
           const int64_t ov = ((int64_t)(n * a.OD + d * a.KD + td) * a.OH + h * a.KH + th) * a.OW + w * a.KW + tw;
           val = load_piece(nsrc + ov * a.ldn, c, a.N);
         }
@@ -320,6 +320,7 @@ static bool convT_wide(const devis_convT_desc* d) { return d->Cin > 128 && d->Ci
 
 static bool convT_wgrad_ok(const devis_convT_desc* d) {
   if (d->dtype != DEVIS_BF16 || d->Cin % 8 || d->Cout % 8) return false;
+  if (d->N * d->ID * d->IH * d->IW * d->KD * d->KH * d->KW >= ((int64_t)1 << 31)) return false;   // 32-bit voxel indices
   return convT_wide(d) || pw_tiles_ok((int)d->Cin, (int)d->Cout);
 }
 
@@ -353,7 +354,8 @@ int convT_wgrad_mfma(const devis_convT_desc* d, const void* x, const void* dy, f
 static bool down_wgrad_ok(const devis_conv_desc* d) {
   return d->dtype == DEVIS_BF16 && d->KD == 2 && d->KH == 2 && d->KW == 2 && d->SD == 2 && d->SH == 2 && d->SW == 2 &&
          d->PD == 0 && d->PH == 0 && d->PW == 0 && d->C2 == 0 && d->ID == 2 * d->OD && d->IH == 2 * d->OH &&
-         d->IW == 2 * d->OW && d->C1 % 8 == 0 && d->Cout % 8 == 0 && pw_tiles_ok((int)d->Cout, (int)d->C1);
+         d->IW == 2 * d->OW && d->C1 % 8 == 0 && d->Cout % 8 == 0 && pw_tiles_ok((int)d->Cout, (int)d->C1) &&
+         d->N * d->ID * d->IH * d->IW < ((int64_t)1 << 31);
 }
 
 size_t conv2s2_wgrad_mfma_workspace(const devis_conv_desc* d) {
