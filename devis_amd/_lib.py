@@ -81,6 +81,10 @@ SIGNATURES = {
     "devis_convT_dgrad": (_I, [_CTD, _P, _P, _P, _P, _P]),
     "devis_convT_wgrad_workspace_bytes": (_SZ, [_CTD]),
     "devis_convT_wgrad": (_I, [_CTD, _P, _P, _P, _P, _P, _SZ, _P]),
+    "devis_upcat_supported": (_I, [_I64, _I64, _I64, _I64, _I64, _I]),
+    "devis_upcat_prepare": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
+    "devis_upcat_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
+    "devis_upcat_grad_combine": (_I, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "devis_moments_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "devis_channel_moments": (_I, [_P, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
     "devis_gn_finalize": (_I, [_P, _I64, _I64, _I64, _I64, _P, _P, _F, _P, _P, _P, _P, _P]),

@@ -1,0 +1,199 @@
+// DeUp_Cat tail fused (bf16 channels-last, gfx950): the reference's
+//     up = ConvTranspose3d(C, C, k=2, s=2)(t);  y = Conv3d(2C, C, k=1)(cat((prev, up), 1))      (UNet3DZoo.py:121-129)
+// is ONE pass  y[v] = W3a prev[v] + M[parity(v)] t[coarse(v)] + b'  with the composite matrices
+//     M[p] = W3b Wt[p]  (C x C, one per 2x2x2 parity p),  b' = b3 + W3b bt,   W3 = [W3a | W3b]:
+// `up` (a full-resolution C-channel tensor: written once, read once) never exists, and neither does its gradient.
+// HBM bytes per fine voxel: read C*s (prev) + C*s/8 (t), write C*s  -  against 4 C*s + C*s/8 for the two layers.
+// Backward uses the same matrices: d prev = W3a^T dy (1x1 dgrad), d t = sum_p M[p]^T dy[fine(p)] (the k2-s2 gather
+// GEMM on `wq`), and the two weight gradients come from  dW3a = dy (x) prev  and  G[p] = dy[fine(p)] (x) t  (the 1x1 and
+// the ConvT weight-gradient kernels) through k_upcat_combine:
+//     dW3b = sum_p G[p] Wt[p]^T + s bt^T,  dWt[p] = W3b^T G[p],  db3 = s = sum_v dy[v],  dbt = W3b^T s.
+#include "common.h"
+#include "mfma_common.h"
+
+namespace devis {
+
+struct UpcatArgs {
+  const bf16* prev; const bf16* t; const bf16* wc; const float* bias; bf16* y;
+  int N, D, H, W;          // COARSE grid (t); prev / y are (2D, 2H, 2W)
+  int ntw;                 // 16-voxel coarse tiles per row
+  unsigned ntiles;
+};
+
+// ---- C = 16.  A wave takes 16 consecutive coarse voxels of one row = 2 x 2 x 32 fine voxels.  K = 32 = 16 prev
+// channels + 16 t channels: one MFMA per parity class and 16 fine voxels.  One 64-lane load fetches a whole 1 KB
+// fine row segment: lanes lq = 0,1 hold the two 16-byte halves of fine voxel 2j, lanes lq = 2,3 those of voxel
+// 2j+1; t is loaded in all four lane groups.  The even-w MFMA takes [prev | t] as its K order, the odd-w one
+// [t | prev] (its weight rows are stored with the halves swapped), so no operand crosses lanes.  After the MFMAs a
+// lane owns 4 couts of voxel 2j and 4 of voxel 2j+1; lane pairs (lq, lq^1) swap one of them so that every lane
+// stores 16 contiguous bytes and a wave store covers the 1 KB row segment exactly.
+template <int TPW>
+__global__ void __launch_bounds__(256)
+k_upcat16_fwd(UpcatArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const bool lo = lq < 2, odd = lq & 1;
+  union U { uint4 u; bf16x8 v; u32x4 w; };
+  U af[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) af[p].u = *reinterpret_cast<const uint4*>(a.wc + ((p * 16 + l15) * 32 + lq * 8));
+  const float4 bb = *reinterpret_cast<const float4*>(a.bias + lq * 4);
+  const int D2 = 2 * a.D, H2 = 2 * a.H, W2 = 2 * a.W;
+  (void)D2;
+  uint4 pl[TPW][4], tl[TPW];
+  size_t rowb[TPW][4];
+  bool ok[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const unsigned tile = ((unsigned)blockIdx.x * 4u + (unsigned)wave) * TPW + i;
+    ok[i] = tile < a.ntiles;
+    const unsigned tt = ok[i] ? tile : 0u;
+    const int twi = (int)(tt % (unsigned)a.ntw);
+    unsigned r = tt / (unsigned)a.ntw;
+    const int h = (int)(r % (unsigned)a.H); r /= (unsigned)a.H;
+    const int d = (int)(r % (unsigned)a.D);
+    const int n = (int)(r / (unsigned)a.D);
+    const int w0 = twi * 16;
+    tl[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (ok[i]) tl[i] = *reinterpret_cast<const uint4*>(a.t + ((((size_t)n * a.D + d) * a.H + h) * a.W + w0 + l15) * 16 + odd * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pd = q >> 1, ph = q & 1;
+      // element offset of this lane's 16-byte piece of fine row (2d+pd, 2h+ph), fine voxels 2*w0 .. 2*w0+31
+      rowb[i][q] = ((((size_t)n * D2 + 2 * d + pd) * H2 + 2 * h + ph) * W2 + 2 * w0 + 2 * l15 + (lq >> 1)) * 16 + odd * 8;
+      pl[i][q] = make_uint4(0u, 0u, 0u, 0u);
+      if (ok[i]) pl[i][q] = *reinterpret_cast<const uint4*>(a.prev + rowb[i][q]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    if (!ok[i]) continue;                      // wave-uniform
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      U b0, b1;
+      b0.u = lo ? pl[i][q] : tl[i];            // even w: K = [prev(2j) | t]
+      b1.u = lo ? tl[i] : pl[i][q];            // odd w:  K = [t | prev(2j+1)]
+      const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q * 2].v, b0.v, z, 0, 0, 0);
+      f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q * 2 + 1].v, b1.v, z, 0, 0, 0);
+      // lane: couts lq*4..+3 of fine voxels 2j (c0) and 2j+1 (c1)
+      const unsigned o00 = pack_bf2(c0[0] + bb.x, c0[1] + bb.y), o01 = pack_bf2(c0[2] + bb.z, c0[3] + bb.w);
+      const unsigned o10 = pack_bf2(c1[0] + bb.x, c1[1] + bb.y), o11 = pack_bf2(c1[2] + bb.z, c1[3] + bb.w);
+      // even lq keeps voxel 2j and gets couts (lq+1)*4.. of it from lane+16; odd lq keeps voxel 2j+1
+      const unsigned s0 = odd ? o00 : o10, s1 = odd ? o01 : o11;
+      const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16, 64), r1 = (unsigned)__shfl_xor((int)s1, 16, 64);
+      const uint4 out = odd ? make_uint4(r0, r1, o10, o11) : make_uint4(o00, o01, r0, r1);
+      // voxel 2j + odd, couts (lq>>1)*8 .. +7
+      const size_t off = rowb[i][q] - (size_t)((lq >> 1) * 16 + odd * 8) + (size_t)(odd * 16 + (lq >> 1) * 8);
+      *reinterpret_cast<uint4*>(a.y + off) = out;
+    }
+  }
+}
+
+// ---- composite weights of one DeUp_Cat (one block; C <= 64).  fp32 masters in, kernel layouts out:
+//   wc   bf16 [8][C][2C]: parity p = (pd*2+ph)*2+pw; even pw rows = [W3a | M[p]], odd pw rows = [M[p] | W3a]
+//   bias fp32 [C]       : b3 + W3b bt
+//   w3a  bf16 [C][C]    : W3a as a packed 1x1 conv weight [Cout][1][Cin];  w3a_t: its dgrad packing [Cin][1][Cout]
+//   wq   bf16 [C][8][C] : wq[c][p][o] = M[p][o][c] - the k2-s2 'down conv' packing [Cout][T][Cin] of d t = sum_p M[p]^T dy
+__global__ void __launch_bounds__(256)
+k_upcat_prepare(const float* __restrict__ w3, const float* __restrict__ b3, const float* __restrict__ wt,
+                const float* __restrict__ bt, int C, bf16* __restrict__ wc, float* __restrict__ bias,
+                bf16* __restrict__ w3a, bf16* __restrict__ w3a_t, bf16* __restrict__ wq) {
+  const int K2 = 2 * C;
+  for (int i = threadIdx.x; i < 8 * C * C; i += blockDim.x) {
+    const int c = i % C, o = (i / C) % C, p = i / (C * C);
+    float m = 0.f;
+    for (int k = 0; k < C; ++k) m = fmaf(w3[o * K2 + C + k], wt[(c * C + k) * 8 + p], m);
+    const bool oddw = p & 1;
+    wc[(p * C + o) * K2 + (oddw ? 0 : C) + c] = (bf16)m;
+    wc[(p * C + o) * K2 + (oddw ? C : 0) + c] = (bf16)w3[o * K2 + c];
+    wq[(c * 8 + p) * C + o] = (bf16)m;
+  }
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+    const int c = i % C, o = i / C;
+    w3a[o * C + c] = (bf16)w3[o * K2 + c];
+    w3a_t[c * C + o] = (bf16)w3[o * K2 + c];
+  }
+  for (int o = threadIdx.x; o < C; o += blockDim.x) {
+    float b = b3[o];
+    for (int k = 0; k < C; ++k) b = fmaf(w3[o * K2 + C + k], bt[k], b);
+    bias[o] = b;
+  }
+}
+
+// ---- weight gradients of conv3 / conv2 from the fused kernels' sums (one block, fixed summation order):
+//   g [C(c)][C(o)][8] = sum_i t[i][c] dy[fine(i,p)][o]   (ConvT weight-gradient layout),  dw3a [C(o)][C(k)],  s [C]
+__global__ void __launch_bounds__(256)
+k_upcat_combine(const float* __restrict__ g, const float* __restrict__ dw3a, const float* __restrict__ s,
+                const float* __restrict__ w3, const float* __restrict__ wt, const float* __restrict__ bt, int C,
+                float* __restrict__ dw3, float* __restrict__ db3, float* __restrict__ dwt, float* __restrict__ dbt) {
+  const int K2 = 2 * C;
+  for (int i = threadIdx.x; i < C * K2; i += blockDim.x) {
+    const int k = i % K2, o = i / K2;
+    float v;
+    if (k < C) v = dw3a[o * C + k];
+    else {
+      const int m = k - C;
+      v = s[o] * bt[m];
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v = fmaf(g[(c * C + o) * 8 + p], wt[(c * C + m) * 8 + p], v);
+    }
+    dw3[i] = v;
+  }
+  for (int i = threadIdx.x; i < C * C * 8; i += blockDim.x) {
+    const int p = i % 8, m = (i / 8) % C, c = i / (8 * C);
+    float v = 0.f;
+    for (int o = 0; o < C; ++o) v = fmaf(w3[o * K2 + C + m], g[(c * C + o) * 8 + p], v);
+    dwt[i] = v;
+  }
+  for (int m = threadIdx.x; m < C; m += blockDim.x) {
+    db3[m] = s[m];
+    float v = 0.f;
+    for (int o = 0; o < C; ++o) v = fmaf(w3[o * K2 + C + m], s[o], v);
+    dbt[m] = v;
+  }
+}
+
+}  // namespace devis
+
+using namespace devis;
+
+extern "C" {
+
+int devis_upcat_supported(int64_t N, int64_t D, int64_t H, int64_t W, int64_t C, int dtype) {
+  if (dtype != DEVIS_BF16 || C != 16 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || W % 16) return 0;
+  return N * D * H * W * 8 < ((int64_t)1 << 31) ? 1 : 0;
+}
+
+int devis_upcat_prepare(const float* w3, const float* b3, const float* wt, const float* bt, int64_t C, void* wc,
+                        float* bias, void* w3a, void* w3a_t, void* wq, void* stream) {
+  if (!w3 || !b3 || !wt || !bt || !wc || !bias || !w3a || !w3a_t || !wq || C <= 0 || C > 64) return DEVIS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_upcat_prepare, dim3(1), dim3(256), 0, (hipStream_t)stream, w3, b3, wt, bt, (int)C, (bf16*)wc, bias,
+                     (bf16*)w3a, (bf16*)w3a_t, (bf16*)wq);
+  return launch_status();
+}
+
+int devis_upcat_fwd(const void* prev, const void* t, const void* wc, const float* bias, void* y, int64_t N, int64_t D,
+                    int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+  if (!prev || !t || !wc || !bias || !y) return DEVIS_ERR_BAD_ARG;
+  if (!devis_upcat_supported(N, D, H, W, C, dtype)) return DEVIS_ERR_UNSUPPORTED;
+  UpcatArgs a;
+  a.prev = (const bf16*)prev; a.t = (const bf16*)t; a.wc = (const bf16*)wc; a.bias = bias; a.y = (bf16*)y;
+  a.N = (int)N; a.D = (int)D; a.H = (int)H; a.W = (int)W;
+  a.ntw = (int)(W / 16);
+  a.ntiles = (unsigned)(N * D * H * a.ntw);
+  constexpr int TPW = 2;
+  hipLaunchKernelGGL((k_upcat16_fwd<TPW>), dim3((unsigned)cdiv(a.ntiles, 4 * TPW)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int devis_upcat_grad_combine(const float* g, const float* dw3a, const float* s, const float* w3, const float* wt,
+                             const float* bt, int64_t C, float* dw3, float* db3, float* dwt, float* dbt, void* stream) {
+  if (!g || !dw3a || !s || !w3 || !wt || !bt || !dw3 || !db3 || !dwt || !dbt || C <= 0 || C > 64) return DEVIS_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_upcat_combine, dim3(1), dim3(256), 0, (hipStream_t)stream, g, dw3a, s, w3, wt, bt, (int)C, dw3, db3,
+                     dwt, dbt);
+  return launch_status();
+}
+
+}  // extern "C"

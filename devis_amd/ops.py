@@ -400,6 +400,56 @@ def convT_wgrad(x: Tensor, dy: Tensor, k, wshape, out=None, slot: str = "ws"):
     return dw, db
 
 
+# ------------------------------------------------------- fused DeUp_Cat tail
+def upcat_supported(prev: Tensor, t: Tensor) -> bool:
+    """True when the fused ConvT(k2,s2) + cat + 1x1 kernel (csrc/upcat.hip) takes these tensors."""
+    if prev.dtype != torch.bfloat16 or t.dtype != torch.bfloat16 or t.dim() != 5 or prev.dim() != 5:
+        return False
+    n, d, h, w, c = t.shape
+    if tuple(prev.shape) != (n, 2 * d, 2 * h, 2 * w, c):
+        return False
+    return bool(_lib.load().devis_upcat_supported(n, d, h, w, c, dt_code(t.dtype)))
+
+
+def upcat_prepare(w3: Tensor, b3: Tensor, wt: Tensor, bt: Tensor):
+    """fp32 masters of DeUp_Cat.conv3 / conv2 -> dict of the composite weights in the kernels' layouts."""
+    _need_cuda(w3, b3, wt, bt)
+    c = wt.shape[1]
+    if tuple(w3.shape[:2]) != (c, 2 * c) or wt.shape[0] != c or wt.numel() != c * c * 8:
+        raise _lib.DevisError("upcat: conv3 must be (C, 2C, 1, 1, 1) and conv2 (C, C, 2, 2, 2)")
+    bf = dict(dtype=torch.bfloat16, device=w3.device)
+    arena = torch.empty((8 * c * 2 * c + 2 * c * c + 8 * c * c,), **bf)
+    o1 = 8 * c * 2 * c
+    m = {"wc": arena[:o1].view(8, c, 2 * c), "w3a": arena[o1:o1 + c * c].view(c, 1, c),
+         "w3a_t": arena[o1 + c * c:o1 + 2 * c * c].view(c, 1, c), "wq": arena[o1 + 2 * c * c:].view(c, 8, c),
+         "bias": torch.empty((c,), dtype=torch.float32, device=w3.device), "C": c}
+    check(_lib.load().devis_upcat_prepare(_p(w3.detach()), _p(b3.detach()), _p(wt.detach()), _p(bt.detach()), c, _p(m["wc"]),
+                                          _p(m["bias"]), _p(m["w3a"]), _p(m["w3a_t"]), _p(m["wq"]), _stream()), "upcat_prepare")
+    return m
+
+
+def upcat_fwd(prev: Tensor, t: Tensor, m) -> Tensor:
+    """y = conv3(cat((prev, convT(t)), 1)) in one pass (UNet3DZoo.py:121-129)."""
+    _need_cuda(prev, t)
+    n, d, h, w, c = t.shape
+    if tuple(prev.shape) != (n, 2 * d, 2 * h, 2 * w, c) or c != m["C"]:
+        raise _lib.DevisError("upcat: prev must be the (2D, 2H, 2W) tensor with t's channels")
+    y = torch.empty_like(prev)
+    check(_lib.load().devis_upcat_fwd(_p(prev), _p(t), _p(m["wc"]), _p(m["bias"]), _p(y), n, d, h, w, c, dt_code(t.dtype),
+                                      _stream()), "upcat_fwd")
+    return y
+
+
+def upcat_grad_combine(g: Tensor, dw3a: Tensor, s: Tensor, w3: Tensor, wt: Tensor, bt: Tensor, out, slot: str = "ws"):
+    """(G, dW3a, s) of the fused backward -> (dw3, db3, dwt, dbt) written into the buffers `out`."""
+    dw3, db3, dwt, dbt = out
+    _check_out(dw3, db3, dwt, dbt, g, dw3a, s)
+    c = wt.shape[1]
+    check(_lib.load().devis_upcat_grad_combine(_p(g), _p(dw3a), _p(s), _p(w3.detach()), _p(wt.detach()), _p(bt.detach()), c,
+                                               _p(dw3), _p(db3), _p(dwt), _p(dbt), _stream()), "upcat_grad_combine")
+    return out
+
+
 # -------------------------------------------------------------------- norm
 def _nvc(x: Tensor):
     n, c = x.shape[0], x.shape[-1]

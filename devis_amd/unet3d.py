@@ -25,6 +25,10 @@ Tensor = torch.Tensor
 G3 = ConvGeom((3, 3, 3), (1, 1, 1), (1, 1, 1))
 G3S2 = ConvGeom((3, 3, 3), (2, 2, 2), (1, 1, 1))
 G1 = ConvGeom((1, 1, 1), (1, 1, 1), (0, 0, 0))
+G2S2 = ConvGeom((2, 2, 2), (2, 2, 2), (0, 0, 0))
+# DEVIS_NO_UPCAT_FUSE=1: run DeUp_Cat's ConvT and 1x1 as two layers (the path every unsupported shape takes)
+import os as _os
+_UPCAT_FUSE = _os.environ.get("DEVIS_NO_UPCAT_FUSE", "0") != "1"
 
 
 # ------------------------------------------------------------ parameter holders
@@ -137,6 +141,13 @@ class _Run:
     def de_up_cat(self, name, x, prev):
         w1 = self._w(name + ".conv1")
         t = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G1)
+        if _UPCAT_FUSE and ops.upcat_supported(prev, t):
+            # ConvT + cat + 1x1 in one pass on composite weights (csrc/upcat.hip): `up` is never written
+            m = ops.upcat_prepare(self.P[name + ".conv3.weight"], self.P[name + ".conv3.bias"],
+                                  self.P[name + ".conv2.weight"], self.P[name + ".conv2.bias"])
+            y = ops.upcat_fwd(prev, t, m)
+            self._push("upf", name, x, prev, t, m, w1)
+            return y
         wt = self._w(name + ".conv2")
         up = ops.convT_fwd(t, wt, self.P[name + ".conv2.bias"], (2, 2, 2))
         w3 = self._w(name + ".conv3")
@@ -236,14 +247,30 @@ class _Run:
         return ops.conv_dgrad(dh1, w1, G3, x.shape, residual=dout, wd=self._wd(name + ".conv1"))[0]
 
     def _up_bwd(self, e, dy):
-        _, name, x, prev, t, up, w1, wt, w3 = e
         g, P = self.grads, self.P
-        g[name + ".conv3.weight"], g[name + ".conv3.bias"] = self._wg(
-            ops.conv_wgrad, prev, up, dy, G1, P[name + ".conv3.weight"].shape, out=self._o(name + ".conv3"))
-        dprev, dup = ops.conv_dgrad(dy, w3, G1, prev.shape, up.shape[-1], wd=self._wd(name + ".conv3"))
-        g[name + ".conv2.weight"], g[name + ".conv2.bias"] = self._wg(
-            ops.convT_wgrad, t, dup, (2, 2, 2), P[name + ".conv2.weight"].shape, out=self._o(name + ".conv2"))
-        dt = ops.convT_dgrad(dup, wt, (2, 2, 2), t.shape, wt=self._wd(name + ".conv2"))
+        if e[0] == "upf":
+            _, name, x, prev, t, m, w1 = e
+            c = m["C"]
+            f = dict(dtype=torch.float32, device=dy.device)
+            tmp = torch.empty((c * c * 8 + c * c + 2 * c,), **f)      # G, dW3a, s (twice: both kernels leave sum dy)
+            gG, gA = tmp[:c * c * 8].view(c, c, 2, 2, 2), tmp[c * c * 8:c * c * 9].view(c, c, 1, 1, 1)
+            s1, s2 = tmp[c * c * 9:c * c * 9 + c], tmp[c * c * 9 + c:]
+            self._wg(ops.conv_wgrad, prev, None, dy, G1, gA.shape, out=(gA, s1))
+            self._wg(ops.convT_wgrad, t, dy, (2, 2, 2), gG.shape, out=(gG, s2))
+            self._wg(ops.upcat_grad_combine, gG, gA, s1, P[name + ".conv3.weight"], P[name + ".conv2.weight"],
+                     P[name + ".conv2.bias"], out=self._o(name + ".conv3") + self._o(name + ".conv2"))
+            for k in (".conv3.weight", ".conv3.bias", ".conv2.weight", ".conv2.bias"):
+                g[name + k] = self.G[name + k]
+            dprev = ops.conv_dgrad(dy, m["w3a"], G1, prev.shape, wd=m["w3a_t"])[0]
+            dt = ops.conv_fwd(dy, None, m["wq"], None, G2S2)          # d t = sum_p M[p]^T dy[fine(p)]
+        else:
+            _, name, x, prev, t, up, w1, wt, w3 = e
+            g[name + ".conv3.weight"], g[name + ".conv3.bias"] = self._wg(
+                ops.conv_wgrad, prev, up, dy, G1, P[name + ".conv3.weight"].shape, out=self._o(name + ".conv3"))
+            dprev, dup = ops.conv_dgrad(dy, w3, G1, prev.shape, up.shape[-1], wd=self._wd(name + ".conv3"))
+            g[name + ".conv2.weight"], g[name + ".conv2.bias"] = self._wg(
+                ops.convT_wgrad, t, dup, (2, 2, 2), P[name + ".conv2.weight"].shape, out=self._o(name + ".conv2"))
+            dt = ops.convT_dgrad(dup, wt, (2, 2, 2), t.shape, wt=self._wd(name + ".conv2"))
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = self._wg(
             ops.conv_wgrad, x, None, dt, G1, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
         norm = self._next_norm()

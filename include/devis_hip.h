@@ -162,6 +162,25 @@ size_t devis_convT_wgrad_workspace_bytes(const devis_convT_desc* d);
 int devis_convT_wgrad(const devis_convT_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* DeUp_Cat tail fused (3-D U-Net decoder, UNet3DZoo.py:121-129: ConvTranspose3d(C,C,2,2) -> cat((prev, up), 1) ->
+ * Conv3d(2C, C, 1)).  One pass y[v] = W3a prev[v] + M[parity(v)] t[coarse(v)] + b' with the composite matrices
+ * M[p] = W3b Wt[p], b' = b3 + W3b bt: the up-sampled tensor and its gradient are never written.
+ * (N, D, H, W) is the COARSE grid of t; prev / y are channels-last (N, 2D, 2H, 2W, C).  bf16 only.
+ * devis_upcat_supported: 1 when devis_upcat_fwd takes the shape (else run the two layers separately).
+ * devis_upcat_prepare (fp32 masters: w3 = conv3.weight [C][2C], b3, wt = conv2.weight [C][C][8], bt) fills
+ *   wc [8][C][2C] bf16 (forward), bias [C] fp32, w3a [C][1][C] + w3a_t (packed 1x1 weight of the prev half and its
+ *   dgrad packing: d prev = devis_conv_dgrad on them), wq [C][8][C] bf16 (k2-s2 conv packing: d t = devis_conv_fwd
+ *   of dy with kernel = stride = 2 on it).
+ * devis_upcat_grad_combine: g = devis_convT_wgrad(t, dy) [C][C][8], dw3a = devis_conv_wgrad(prev, dy) [C][C],
+ *   s = its dbias -> dw3 [C][2C], db3, dwt [C][C][8], dbt (the reference's conv3 / conv2 parameter gradients). */
+int devis_upcat_supported(int64_t N, int64_t D, int64_t H, int64_t W, int64_t C, int dtype);
+int devis_upcat_prepare(const float* w3, const float* b3, const float* wt, const float* bt, int64_t C, void* wc,
+                        float* bias, void* w3a, void* w3a_t, void* wq, void* stream);
+int devis_upcat_fwd(const void* prev, const void* t, const void* wc, const float* bias, void* y, int64_t N, int64_t D,
+                    int64_t H, int64_t W, int64_t C, int dtype, void* stream);
+int devis_upcat_grad_combine(const float* g, const float* dw3a, const float* s, const float* w3, const float* wt,
+                             const float* bt, int64_t C, float* dw3, float* db3, float* dwt, float* dbt, void* stream);
+
 /* ------------------------------------------------------- normalisation -- */
 /* per-(n,c) moments of a channels-last tensor: out[n][c] = {sum x, sum x^2} (fp64).
  * First half of nn.GroupNorm / nn.BatchNorm forward (UNet3DZoo.py:12,149,153; UNet2DZoo.py:13,16). */
