@@ -90,68 +90,196 @@ k_upcat16_fwd(UpcatArgs a) {
   }
 }
 
-// ---- composite weights of one DeUp_Cat (one block; C <= 64).  fp32 masters in, kernel layouts out:
+// ---- C = 32.  K = 64 = two MFMA K steps (32 prev channels, 32 t channels), 32 couts = two M tiles.  A wave takes
+// 16 coarse voxels; per fine row (pd, ph) and w parity it loads fine voxels 2j+pw (64 B each: four lanes), so the
+// two parities' loads and stores interleave in the same 2 KB row segment.  The W3a fragments are shared by all
+// parities (2 fragments), the M[p] fragments (16) stay in registers as well.  After the MFMAs lane pairs (lq, lq^1)
+// swap one M tile, so a lane stores 8 consecutive couts (16 B) and four lanes cover a voxel's 64-byte row.
+__global__ void __launch_bounds__(256)
+k_upcat32_fwd(UpcatArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const bool odd = lq & 1;
+  union U { uint4 u; bf16x8 v; };
+  U wa[2], wm[8][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    wa[mt].u = *reinterpret_cast<const uint4*>(a.wc + ((size_t)(mt * 16 + l15) * 64 + lq * 8));          // parity 0: [W3a | M]
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      wm[p][mt].u = *reinterpret_cast<const uint4*>(a.wc + ((size_t)((p * 32 + mt * 16 + l15) * 64) + ((p & 1) ? 0 : 32) + lq * 8));
+  }
+  float4 bb[2];
+  bb[0] = *reinterpret_cast<const float4*>(a.bias + lq * 4);
+  bb[1] = *reinterpret_cast<const float4*>(a.bias + 16 + lq * 4);
+  const unsigned tile = (unsigned)blockIdx.x * 4u + (unsigned)wave;
+  if (tile >= a.ntiles) return;                 // wave-uniform; no barriers in this kernel
+  const int twi = (int)(tile % (unsigned)a.ntw);
+  unsigned r = tile / (unsigned)a.ntw;
+  const int h = (int)(r % (unsigned)a.H); r /= (unsigned)a.H;
+  const int d = (int)(r % (unsigned)a.D);
+  const int n = (int)(r / (unsigned)a.D);
+  const int w0 = twi * 16;
+  const int D2 = 2 * a.D, H2 = 2 * a.H, W2 = 2 * a.W;
+  (void)D2;
+  U tl, pl[8];
+  size_t vox[8];
+  tl.u = *reinterpret_cast<const uint4*>(a.t + ((((size_t)n * a.D + d) * a.H + h) * a.W + w0 + l15) * 32 + lq * 8);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
+    vox[p] = (((size_t)n * D2 + 2 * d + pd) * H2 + 2 * h + ph) * W2 + 2 * (w0 + l15) + pw;
+    pl[p].u = *reinterpret_cast<const uint4*>(a.prev + vox[p] * 32 + lq * 8);
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    unsigned o[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt].v, pl[p].v, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[p][mt].v, tl.v, c, 0, 0, 0);
+      o[mt][0] = pack_bf2(c[0] + bb[mt].x, c[1] + bb[mt].y);
+      o[mt][1] = pack_bf2(c[2] + bb[mt].z, c[3] + bb[mt].w);
+    }
+    // even lq keeps M tile 0 (couts lq*4 .. +7 with lane+16's half), odd lq keeps M tile 1 (couts 16 + (lq-1)*4 .. +7)
+    const unsigned s0 = odd ? o[0][0] : o[1][0], s1 = odd ? o[0][1] : o[1][1];
+    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16, 64), r1 = (unsigned)__shfl_xor((int)s1, 16, 64);
+    const uint4 out = odd ? make_uint4(r0, r1, o[1][0], o[1][1]) : make_uint4(o[0][0], o[0][1], r0, r1);
+    const int choff = odd ? 16 + (lq - 1) * 4 : lq * 4;
+    *reinterpret_cast<uint4*>(a.y + vox[p] * 32 + choff) = out;
+  }
+}
+
+// ---- composite weights of one DeUp_Cat (grid = 8 blocks, one per parity p; C <= 64).  fp32 masters in, kernel
+// layouts out:
 //   wc   bf16 [8][C][2C]: parity p = (pd*2+ph)*2+pw; even pw rows = [W3a | M[p]], odd pw rows = [M[p] | W3a]
 //   bias fp32 [C]       : b3 + W3b bt
 //   w3a  bf16 [C][C]    : W3a as a packed 1x1 conv weight [Cout][1][Cin];  w3a_t: its dgrad packing [Cin][1][Cout]
 //   wq   bf16 [C][8][C] : wq[c][p][o] = M[p][o][c] - the k2-s2 'down conv' packing [Cout][T][Cin] of d t = sum_p M[p]^T dy
+// The two C x C factors of the block's parity are staged in LDS (rows padded by one float: conflict-free).
 __global__ void __launch_bounds__(256)
 k_upcat_prepare(const float* __restrict__ w3, const float* __restrict__ b3, const float* __restrict__ wt,
                 const float* __restrict__ bt, int C, bf16* __restrict__ wc, float* __restrict__ bias,
                 bf16* __restrict__ w3a, bf16* __restrict__ w3a_t, bf16* __restrict__ wq) {
-  const int K2 = 2 * C;
-  for (int i = threadIdx.x; i < 8 * C * C; i += blockDim.x) {
-    const int c = i % C, o = (i / C) % C, p = i / (C * C);
-    float m = 0.f;
-    for (int k = 0; k < C; ++k) m = fmaf(w3[o * K2 + C + k], wt[(c * C + k) * 8 + p], m);
-    const bool oddw = p & 1;
-    wc[(p * C + o) * K2 + (oddw ? 0 : C) + c] = (bf16)m;
-    wc[(p * C + o) * K2 + (oddw ? C : 0) + c] = (bf16)w3[o * K2 + c];
-    wq[(c * 8 + p) * C + o] = (bf16)m;
+  __shared__ float sW[64 * 65], sT[64 * 65];       // W3b[o][m], Wt[.][.][p] as [c][m]
+  const int K2 = 2 * C, p = blockIdx.x, LD = C + 1;
+  for (int i0 = threadIdx.x; i0 < C * C; i0 += 256 * 4) {        // all loads of a round before the LDS stores
+    float vw[4], vt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u, m = i % C, r = i / C;
+      if (i < C * C) { vw[u] = w3[r * K2 + C + m]; vt[u] = wt[(r * C + m) * 8 + p]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u, m = i % C, r = i / C;
+      if (i < C * C) { sW[r * LD + m] = vw[u]; sT[r * LD + m] = vt[u]; }
+    }
   }
+  __syncthreads();
+  const bool oddw = p & 1;
   for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
     const int c = i % C, o = i / C;
-    w3a[o * C + c] = (bf16)w3[o * K2 + c];
-    w3a_t[c * C + o] = (bf16)w3[o * K2 + c];
+    float m = 0.f;
+    for (int k = 0; k < C; ++k) m = fmaf(sW[o * LD + k], sT[c * LD + k], m);
+    const float a = w3[o * K2 + c];
+    wc[(p * C + o) * K2 + (oddw ? 0 : C) + c] = (bf16)m;
+    wc[(p * C + o) * K2 + (oddw ? C : 0) + c] = (bf16)a;
+    wq[(c * 8 + p) * C + o] = (bf16)m;
+    if (p == 0) { w3a[o * C + c] = (bf16)a; w3a_t[c * C + o] = (bf16)a; }
   }
-  for (int o = threadIdx.x; o < C; o += blockDim.x) {
-    float b = b3[o];
-    for (int k = 0; k < C; ++k) b = fmaf(w3[o * K2 + C + k], bt[k], b);
-    bias[o] = b;
-  }
+  if (p == 0)
+    for (int o = threadIdx.x; o < C; o += blockDim.x) {
+      float b = b3[o];
+      for (int k = 0; k < C; ++k) b = fmaf(sW[o * LD + k], bt[k], b);
+      bias[o] = b;
+    }
 }
 
-// ---- weight gradients of conv3 / conv2 from the fused kernels' sums (one block, fixed summation order):
+// ---- weight gradients of conv3 / conv2 from the fused backward's sums (fixed summation order: deterministic):
 //   g [C(c)][C(o)][8] = sum_i t[i][c] dy[fine(i,p)][o]   (ConvT weight-gradient layout),  dw3a [C(o)][C(k)],  s [C]
+// C = 16 or 32; grid = 8 + C*C/256 blocks.  Block p < 8: dWt[.][.][p] = W3b^T G[p] (both factors staged in LDS).
+// Block 8 + b: R = 256/C rows of dW3 = [dW3a | sum_p G[p] Wt[p]^T + s bt^T], one thread per entry, Wt and the block's
+// rows of G in LDS (rows padded by one float).  Block 8 also leaves db3 = s and dbt = W3b^T s.
 __global__ void __launch_bounds__(256)
 k_upcat_combine(const float* __restrict__ g, const float* __restrict__ dw3a, const float* __restrict__ s,
                 const float* __restrict__ w3, const float* __restrict__ wt, const float* __restrict__ bt, int C,
                 float* __restrict__ dw3, float* __restrict__ db3, float* __restrict__ dwt, float* __restrict__ dbt) {
-  const int K2 = 2 * C;
-  for (int i = threadIdx.x; i < C * K2; i += blockDim.x) {
-    const int k = i % K2, o = i / K2;
-    float v;
-    if (k < C) v = dw3a[o * C + k];
-    else {
-      const int m = k - C;
-      v = s[o] * bt[m];
-      for (int c = 0; c < C; ++c)
+  extern __shared__ float dyn[];
+  const int K2 = 2 * C, LD = C + 1;
+  if (blockIdx.x < 8) {
+    float* sW = dyn;                 // W3b[o][m]
+    float* sG = dyn + C * LD;        // G[.][.][p] as [c][o]
+    const int p = blockIdx.x;
+    {
+      float vw[4], vg[4];                        // C * C / 256 = 1 or 4 elements per thread, all loads first
 #pragma unroll
-        for (int p = 0; p < 8; ++p) v = fmaf(g[(c * C + o) * 8 + p], wt[(c * C + m) * 8 + p], v);
+      for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + 256 * u, m = i % C, r = i / C;
+        if (i < C * C) { vw[u] = w3[r * K2 + C + m]; vg[u] = g[(r * C + m) * 8 + p]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + 256 * u, m = i % C, r = i / C;
+        if (i < C * C) { sW[r * LD + m] = vw[u]; sG[r * LD + m] = vg[u]; }
+      }
     }
-    dw3[i] = v;
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+      const int m = i % C, c = i / C;
+      float v = 0.f;
+      for (int o = 0; o < C; ++o) v = fmaf(sW[o * LD + m], sG[c * LD + o], v);
+      dwt[(c * C + m) * 8 + p] = v;
+    }
+    return;
   }
-  for (int i = threadIdx.x; i < C * C * 8; i += blockDim.x) {
-    const int p = i % 8, m = (i / 8) % C, c = i / (8 * C);
-    float v = 0.f;
-    for (int o = 0; o < C; ++o) v = fmaf(w3[o * K2 + C + m], g[(c * C + o) * 8 + p], v);
-    dwt[i] = v;
+  // row block: R = 256 / C rows of dW3; thread = (row ol, column m); both operands of the 8C-long dot products in LDS
+  const int R = 256 / C, I = 8 * C, LDI = I + 1;
+  const int o0 = ((int)blockIdx.x - 8) * R;
+  float* sWt = dyn;                   // [m][i = c*8 + p] = Wt[c][m][p]
+  float* sGr = dyn + C * LDI;         // [ol][i]          = G[c][o0 + ol][p]
+  // eight loads in flight per thread (a load -> LDS-store loop left rolled pays one L2 latency per element)
+  for (int L0 = threadIdx.x; L0 < C * I; L0 += 256 * 8) {       // C * I = 8 C^2 is a multiple of 2048
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = wt[L0 + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int L = L0 + 256 * u, p = L & 7, m = (L >> 3) % C, c = (L >> 3) / C;
+      sWt[m * LDI + c * 8 + p] = v[u];
+    }
   }
-  for (int m = threadIdx.x; m < C; m += blockDim.x) {
-    db3[m] = s[m];
+  for (int L0 = threadIdx.x; L0 < R * I; L0 += 256 * 8) {       // R * I = 2048
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int L = L0 + 256 * u, p = L & 7, ol = (L >> 3) % R, c = (L >> 3) / R;
+      v[u] = g[(c * C + o0 + ol) * 8 + p];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int L = L0 + 256 * u, p = L & 7, ol = (L >> 3) % R, c = (L >> 3) / R;
+      sGr[ol * LDI + c * 8 + p] = v[u];
+    }
+  }
+  __syncthreads();
+  const int ol = threadIdx.x / C, m = threadIdx.x % C, o = o0 + ol;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float* gr = sGr + ol * LDI;
+  const float* wr = sWt + m * LDI;
+  for (int i = 0; i < I; i += 4) {
+    a0 = fmaf(gr[i], wr[i], a0); a1 = fmaf(gr[i + 1], wr[i + 1], a1);
+    a2 = fmaf(gr[i + 2], wr[i + 2], a2); a3 = fmaf(gr[i + 3], wr[i + 3], a3);
+  }
+  dw3[o * K2 + C + m] = fmaf(s[o], bt[m], (a0 + a1) + (a2 + a3));
+  dw3[o * K2 + m] = dw3a[o * C + m];
+  if (blockIdx.x == 8 && threadIdx.x < C) {
+    const int mm = threadIdx.x;
+    db3[mm] = s[mm];
     float v = 0.f;
-    for (int o = 0; o < C; ++o) v = fmaf(w3[o * K2 + C + m], s[o], v);
-    dbt[m] = v;
+    for (int oo = 0; oo < C; ++oo) v = fmaf(w3[oo * K2 + C + mm], s[oo], v);
+    dbt[mm] = v;
   }
 }
 
@@ -162,14 +290,14 @@ using namespace devis;
 extern "C" {
 
 int devis_upcat_supported(int64_t N, int64_t D, int64_t H, int64_t W, int64_t C, int dtype) {
-  if (dtype != DEVIS_BF16 || C != 16 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || W % 16) return 0;
+  if (dtype != DEVIS_BF16 || (C != 16 && C != 32) || N <= 0 || D <= 0 || H <= 0 || W <= 0 || W % 16) return 0;
   return N * D * H * W * 8 < ((int64_t)1 << 31) ? 1 : 0;
 }
 
 int devis_upcat_prepare(const float* w3, const float* b3, const float* wt, const float* bt, int64_t C, void* wc,
                         float* bias, void* w3a, void* w3a_t, void* wq, void* stream) {
   if (!w3 || !b3 || !wt || !bt || !wc || !bias || !w3a || !w3a_t || !wq || C <= 0 || C > 64) return DEVIS_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_upcat_prepare, dim3(1), dim3(256), 0, (hipStream_t)stream, w3, b3, wt, bt, (int)C, (bf16*)wc, bias,
+  hipLaunchKernelGGL(k_upcat_prepare, dim3(8), dim3(256), 0, (hipStream_t)stream, w3, b3, wt, bt, (int)C, (bf16*)wc, bias,
                      (bf16*)w3a, (bf16*)w3a_t, (bf16*)wq);
   return launch_status();
 }
@@ -184,15 +312,18 @@ int devis_upcat_fwd(const void* prev, const void* t, const void* wc, const float
   a.ntw = (int)(W / 16);
   a.ntiles = (unsigned)(N * D * H * a.ntw);
   constexpr int TPW = 2;
-  hipLaunchKernelGGL((k_upcat16_fwd<TPW>), dim3((unsigned)cdiv(a.ntiles, 4 * TPW)), dim3(256), 0, (hipStream_t)stream, a);
+  if (C == 16) hipLaunchKernelGGL((k_upcat16_fwd<TPW>), dim3((unsigned)cdiv(a.ntiles, 4 * TPW)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_upcat32_fwd, dim3((unsigned)cdiv(a.ntiles, 4)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
 int devis_upcat_grad_combine(const float* g, const float* dw3a, const float* s, const float* w3, const float* wt,
                              const float* bt, int64_t C, float* dw3, float* db3, float* dwt, float* dbt, void* stream) {
-  if (!g || !dw3a || !s || !w3 || !wt || !bt || !dw3 || !db3 || !dwt || !dbt || C <= 0 || C > 64) return DEVIS_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_upcat_combine, dim3(1), dim3(256), 0, (hipStream_t)stream, g, dw3a, s, w3, wt, bt, (int)C, dw3, db3,
-                     dwt, dbt);
+  if (!g || !dw3a || !s || !w3 || !wt || !bt || !dw3 || !db3 || !dwt || !dbt) return DEVIS_ERR_BAD_ARG;
+  if (C != 16 && C != 32) return DEVIS_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)(C + 256 / C) * (8 * C + 1) * sizeof(float);     // >= the parity blocks' 2 C (C+1) floats
+  hipLaunchKernelGGL(k_upcat_combine, dim3((unsigned)(8 + C * C / 256)), dim3(256), lds, (hipStream_t)stream, g, dw3a, s, w3, wt,
+                     bt, (int)C, dw3, db3, dwt, dbt);
   return launch_status();
 }
 

@@ -17,7 +17,7 @@ def uncl(t):
     return t.float().permute(0, 4, 1, 2, 3).contiguous().cpu()
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 4, 6, 16), (1, 16, 3, 5, 32), (2, 16, 8, 8, 16)])
+@pytest.mark.parametrize("shape", [(2, 16, 4, 6, 16), (1, 16, 3, 5, 32), (2, 16, 8, 8, 16), (2, 32, 3, 4, 16), (1, 32, 5, 2, 48)])
 def test_upcat_forward_and_gradients(shape):
     from devis_amd import ops
     from devis_amd.unet3d import G1, G2S2
@@ -75,4 +75,5 @@ def test_upcat_unsupported_shapes_fall_back():
     z = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device="cuda")
     assert not ops.upcat_supported(z(1, 4, 4, 24, 16), z(1, 2, 2, 12, 16))        # coarse W not a multiple of 16
     assert not ops.upcat_supported(z(1, 4, 4, 32, 8), z(1, 2, 2, 16, 8))          # channels
+    assert not ops.upcat_supported(z(1, 4, 4, 32, 64), z(1, 2, 2, 16, 64))
     assert not ops.upcat_supported(z(1, 4, 4, 32, 16).float(), z(1, 2, 2, 16, 16).float())
