@@ -249,9 +249,256 @@ k_wgrad3_c16_march(WgMarchArgs a) {
   }
 }
 
+// ---- K-split variant (the one launched).  In k_wgrad3_c16_march the four waves share the voxels and split the taps,
+// so every wave reads the whole dy tile and 7 shifted x fragments per K step: 16 transposing LDS reads per 7 MFMAs,
+// 32 KB of LDS traffic per 32 voxels and block - the LDS port, not HBM or the matrix pipe, bounds it (55 us of LDS
+// time at 2 x 128^3).  Here the waves split the VOXELS (wave w takes K steps w and w+4 of a plane's 8) and each keeps
+// all 27 tap accumulators: one dy fragment feeds 27 MFMAs (28 reads per 27 MFMAs, 2.2x less LDS traffic).  The four
+// waves' accumulators are added in wave order through LDS at the end of the walk (once per block).
+template <bool PRO, bool CIN4>
+__global__ void __launch_bounds__(256, 2)
+k_wgrad3_c16_ksplit(WgMarchArgs a) {
+  constexpr int TH = 8, TW = 32;
+  constexpr int HH = TH + 2, HW = TW + 2, HP = HH * HW;
+  constexpr int NPT = (HP * 2 + 255) / 256;
+  constexpr int PLB = NPT * 256 * 16;
+  constexpr int R = 4;
+  constexpr int YPL = TH * TW * 32;
+  constexpr int CINR = CIN4 ? 4 : 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ys = smem + R * PLB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int qq = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
+  }
+  const int twi = tile % a.ntw;
+  const int thi = (tile / a.ntw) % a.nth;
+  const int dci = (tile / (a.ntw * a.nth)) % a.ndc;
+  const int n = tile / (a.ntw * a.nth * a.ndc);
+  const int oh0 = thi * TH, ow0 = twi * TW;
+  const int d0 = dci * a.DL;
+  const int d1 = min(d0 + a.DL, a.D);
+  const size_t plane = (size_t)a.H * a.W;
+
+  unsigned goff[NPT];
+  bool ok[NPT];
+  const int piece = tid & 1;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int i = tid + k * 256;
+    const int u = i >> 1;
+    const int hh = u / HW, hw = u - hh * HW;
+    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+    ok[k] = i < HP * 2 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && !(CIN4 && piece);
+    goff[k] = ok[k] ? (unsigned)((ih * a.W + iw) * CINR + (CIN4 ? 0 : piece * 8)) : 0u;
+  }
+  unsigned yoff[2];
+  bool yok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = (tid + k * 256) >> 1;
+    const int oh = oh0 + v / TW, ow = ow0 + v % TW;
+    yok[k] = oh < a.H && ow < a.W;
+    yoff[k] = yok[k] ? (unsigned)((oh * a.W + ow) * 16 + piece * 8) : 0u;
+  }
+  float scv[8], shv[8];
+  if (PRO) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      scv[j] = a.sc[n * 16 + piece * 8 + j];
+      shv[j] = a.sh[n * 16 + piece * 8 + j];
+    }
+  }
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+  auto load_x = [&](int id, uint4 (&rg)[NPT]) {
+    const int idc = min(max(id, 0), a.D - 1);
+    const bf16* xp = a.x + ((size_t)n * a.D + idc) * plane * CINR;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      if (CIN4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(xp + goff[k]);
+        rg[k] = make_uint4(t.x, t.y, 0u, 0u);
+      } else {
+        rg[k] = *reinterpret_cast<const uint4*>(xp + goff[k]);
+      }
+    }
+  };
+  auto store_x = [&](int id, int slot, uint4 (&rg)[NPT]) {
+    const bool pin = id >= 0 && id < a.D;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      uint4 v = rg[k];
+      if (PRO) v = affine_relu8(v, scv, shv);
+      const bool keep = pin && ok[k];
+      v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+      *reinterpret_cast<uint4*>(smem + slot * PLB + (tid + k * 256) * 16) = v;
+    }
+  };
+  auto load_y = [&](int od, uint4 (&rg)[2]) {
+    const int odc = min(od, a.D - 1);
+    const bf16* yp = a.dy + ((size_t)n * a.D + odc) * plane * 16;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) rg[k] = *reinterpret_cast<const uint4*>(yp + yoff[k]);
+  };
+  auto store_y = [&](int od, int buf, uint4 (&rg)[2]) {
+    const bool pin = od < d1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      uint4 v = rg[k];
+      const bool keep = pin && yok[k];
+      v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+      bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+      bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
+      *reinterpret_cast<uint4*>(ys + buf * YPL + (tid + k * 256) * 16) = v;
+    }
+  };
+
+  {
+    uint4 r0[NPT], r1[NPT], r2[NPT], y0[2];
+    load_x(d0 - 1, r0);
+    load_x(d0, r1);
+    load_x(d0 + 1, r2);
+    load_y(d0, y0);
+    store_x(d0 - 1, 0, r0);
+    store_x(d0, 1, r1);
+    store_x(d0 + 1, 2, r2);
+    store_y(d0, 0, y0);
+  }
+  __syncthreads();
+
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wv = 4 * g + q;
+  const int lanep = wv * 32 + p * 8;
+  // this wave's two K steps of a plane: s = wave, wave + 4 -> (row pair rp = s >> 1, column half h = s & 1)
+  int yo[2], xo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int s = wave + 4 * j, rp = s >> 1, h = s & 1;
+    yo[j] = ((2 * rp) * TW + 16 * h) * 32 + lanep;
+    xo[j] = ((2 * rp) * HW + 16 * h) * 32 + lanep;
+  }
+
+  // The planes stored at the end of iteration `it` (x plane od+2, dy plane od+1) were requested one iteration
+  // EARLIER (prefetch distance 2, two register stages): one plane of MFMAs (about 1.5 us) does not cover an HBM
+  // round trip under load, two do.
+  const int np = d1 - d0;
+  uint4 pxA[NPT], pyA[2], pxB[NPT], pyB[2];
+  load_x(d0 + 2, pxA);
+  load_y(d0 + 1, pyA);
+  auto plane_step = [&](int it, uint4 (&prex)[NPT], uint4 (&prey)[2], uint4 (&nx)[NPT], uint4 (&ny)[2]) __attribute__((always_inline)) {
+    const int od = d0 + it;
+    load_x(od + 3, nx);
+    load_y(od + 2, ny);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const char* yb = ys + (it & 1) * YPL;
+    // group gi = (step j, kd): 9 taps (kh, kw) of x plane it + kd
+    auto read_group = [&](int gi, bf16x8 (&bf)[9]) {
+      const int j = gi / 3, kd = gi % 3;
+      const char* xb = smem + ((it + kd) & (R - 1)) * PLB + xo[j];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int o = ((t / 3) * HW + t % 3) * 32;
+        bf[t] = tr_pair_m(xb + o, xb + o + HW * 32);
+      }
+    };
+    bf16x8 af[2], bA[9], bB[9];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) af[j] = tr_pair_m(yb + yo[j], yb + yo[j] + TW * 32);
+    read_group(0, bA);
+#define KS_INTERLEAVE                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_) {        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      \
+  }
+#pragma unroll
+    for (int gi = 0; gi < 6; gi += 2) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        acc[(gi % 3) * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[gi / 3], bA[t], acc[(gi % 3) * 9 + t], 0, 0, 0);
+      read_group(gi + 1, bB);
+      KS_INTERLEAVE
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        acc[((gi + 1) % 3) * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(gi + 1) / 3], bB[t], acc[((gi + 1) % 3) * 9 + t], 0, 0, 0);
+      if (gi + 2 < 6) read_group(gi + 2, bA);
+      KS_INTERLEAVE
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef KS_INTERLEAVE
+
+    store_x(od + 2, (it + 3) & (R - 1), prex);
+    store_y(od + 1, (it + 1) & 1, prey);
+    __syncthreads();
+  };
+  for (int it = 0; it < np; it += 2) {
+    plane_step(it, pxA, pyA, pxB, pyB);
+    if (it + 1 < np) plane_step(it + 1, pxB, pyB, pxA, pyA);
+  }
+
+  // ---- add the four waves' accumulators in wave order ((w0 + w1) + w2) + w3 through LDS (27 KB per wave)
+  float* red = reinterpret_cast<float*>(smem);            // two regions of 27 * 256 floats
+  if (wave == 1 || wave == 2) {
+    float* r = red + (wave - 1) * 27 * 256;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4*>(r + (t * 64 + lane) * 4) = acc[t];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(red + w * 27 * 256 + (t * 64 + lane) * 4);
+        acc[t][0] += v[0]; acc[t][1] += v[1]; acc[t][2] += v[2]; acc[t][3] += v[3];
+      }
+  }
+  __syncthreads();
+  if (wave == 3) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4*>(red + (t * 64 + lane) * 4) = acc[t];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* part = a.part + (size_t)blockIdx.x * 27 * 256;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(red + (t * 64 + lane) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[(t * 16 + g * 4 + j) * 16 + (lane & 15)] = acc[t][j] + v[j];
+    }
+  }
+  if (a.bpart) {
+    __syncthreads();
+    float* bred = reinterpret_cast<float*>(smem);       // [256][8]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bred[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 16) {
+      const int pc = tid / 8, j = tid % 8;
+      float s = 0.f;
+      for (int k = pc; k < 256; k += 2) s += bred[k * 8 + j];
+      a.bpart[(size_t)blockIdx.x * 16 + tid] = s;
+    }
+  }
+}
+
 static int march_dl(int64_t cols, int D) {
   static int dl_env = -1;
-  if (dl_env < 0) { const char* e = getenv("DEVIS_MARCH_DL"); dl_env = e ? atoi(e) : 0; }
+  if (dl_env < 0) { const char* e = getenv("DEVIS_WGRAD_DL"); dl_env = e ? atoi(e) : 0; }
   if (dl_env > 0) return dl_env;
   int dl = 32;
   while (dl > 8 && cols * cdiv(D, dl) < 512) dl >>= 1;
@@ -280,9 +527,16 @@ int wgrad3_c16_march(const devis_conv_desc* d, const void* x, const float* sc, c
   a.part = (float*)ws; a.bpart = dbias ? (float*)((char*)ws + part_bytes) : nullptr;
   constexpr int LDS = 4 * 3 * 256 * 16 + 2 * 8 * 32 * 32;
   const dim3 grid((unsigned)blocks);
-  if (d->C1 == 4) hipLaunchKernelGGL((k_wgrad3_c16_march<false, true>), grid, dim3(256), LDS, s, a);
-  else if (sc) hipLaunchKernelGGL((k_wgrad3_c16_march<true, false>), grid, dim3(256), LDS, s, a);
-  else hipLaunchKernelGGL((k_wgrad3_c16_march<false, false>), grid, dim3(256), LDS, s, a);
+  static const bool tap_split = getenv("DEVIS_WGRAD_C16_TAPSPLIT") != nullptr;      // the round-1 kernel, for A/B runs
+  if (tap_split) {
+    if (d->C1 == 4) hipLaunchKernelGGL((k_wgrad3_c16_march<false, true>), grid, dim3(256), LDS, s, a);
+    else if (sc) hipLaunchKernelGGL((k_wgrad3_c16_march<true, false>), grid, dim3(256), LDS, s, a);
+    else hipLaunchKernelGGL((k_wgrad3_c16_march<false, false>), grid, dim3(256), LDS, s, a);
+  } else {
+    if (d->C1 == 4) hipLaunchKernelGGL((k_wgrad3_c16_ksplit<false, true>), grid, dim3(256), LDS, s, a);
+    else if (sc) hipLaunchKernelGGL((k_wgrad3_c16_ksplit<true, false>), grid, dim3(256), LDS, s, a);
+    else hipLaunchKernelGGL((k_wgrad3_c16_ksplit<false, false>), grid, dim3(256), LDS, s, a);
+  }
   int rc = launch_status();
   if (rc) return rc;
   return launch_wgrad_reduce(a.part, a.bpart, (int)blocks, 16, 16, (int)d->C1, dw, dbias, s);

@@ -1,0 +1,13 @@
+# PMC passes over tools/time_wgrad_c16.py (the 16-channel weight-gradient kernel at 2 x 128^3)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
+O=gpurun_out/pmc_wgrad
+rm -rf $O && mkdir -p $O
+timeout -s KILL 60 rocprofv3 --list-avail > $O/avail.txt 2>&1
+pass() {
+  n=$1; shift
+  timeout -s KILL 120 rocprofv3 --pmc "$@" -d $O/$n -o $n --output-format csv -- python3 tools/time_wgrad_c16.py > $O/$n.log 2>&1 || { echo pass $n failed; tail -5 $O/$n.log; exit 1; }
+  python3 tools/pmc_summary.py $O/$n wgrad3 > gpurun_out/wgrad_pmc_$n.csv || exit 1
+  cat gpurun_out/wgrad_pmc_$n.csv
+}
+pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY &&
+pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES
