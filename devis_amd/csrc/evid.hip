@@ -366,43 +366,38 @@ __host__ __device__ inline Tversky tversky(double TP, double FP, double FN) {
   return t;
 }
 
-// 1024 threads.  Thread t owns block row t (t, t + 1024, ... when there are more rows): its loads of the used
-// accumulators are independent (all in flight at once), the rows combine in an fp64 xor tree per wave and the 16
-// waves in wave order through LDS - a fixed order, so the result does not depend on the launch.  The K dice terms
-// (fp64 log) are evaluated by K threads side by side.
+// 1024 threads.  The partial table [blocks][EV_NACC] is read as one contiguous array: thread t < 40 * EV_NACC owns
+// column t % EV_NACC of the rows t / EV_NACC, + 40, + 80, ... (a wave load is 512 contiguous bytes, eight loads in
+// flight per thread); the 40 row groups of a column then add up in row-group order through LDS - a fixed order, so
+// the result does not depend on the launch.  The K dice terms (fp64 log) are evaluated by K threads side by side.
 __global__ void __launch_bounds__(1024)
 k_evid_finalize(const double* __restrict__ partial, int blocks, int K, double NV, int kind, float a_au,
                 float* __restrict__ scal) {
-  __shared__ double red[16][EV_NACC];
+  constexpr int RG = 40;
+  __shared__ double red[RG][EV_NACC];
   __shared__ double tot[EV_NACC];
   __shared__ double dterm[EV_MAXK];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  double a[EV_NACC];
+  const int t = threadIdx.x;
+  if (t < RG * EV_NACC) {
+    const int col = t % EV_NACC, rg = t / EV_NACC;
+    const double* p = partial + col;
+    double a = 0.0;
+    int b = rg;
+    for (; b + 7 * RG < blocks; b += 8 * RG) {
+      double v[8];
 #pragma unroll
-  for (int i = 0; i < EV_NACC; ++i) a[i] = 0.0;
-  for (int b = t; b < blocks; b += 1024) {
-    // every slot of a row is written by the forward kernels (zeros for classes >= K): load all 25 without a
-    // predicate, so the loads are issued together and one memory latency covers them
-    const double* row = partial + (int64_t)b * EV_NACC;
-    double v[EV_NACC];
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(b + u * RG) * EV_NACC];
 #pragma unroll
-    for (int i = 0; i < EV_NACC; ++i) v[i] = row[i];
-    __builtin_amdgcn_sched_barrier(0);      // all loads in flight before the first add waits (else: 13 latencies in series)
-#pragma unroll
-    for (int i = 0; i < EV_NACC; ++i) a[i] += v[i];
-  }
-#pragma unroll
-  for (int i = 0; i < EV_NACC; ++i) {
-    if (i == 0 || (i - 1) % EV_MAXK < K) {       // K is uniform: no divergence
-      const double w = wave_sum(a[i]);
-      if (lane == 0) red[wave][i] = w;
+      for (int u = 0; u < 8; ++u) a += v[u];
     }
+    for (; b < blocks; b += RG) a += p[(int64_t)b * EV_NACC];
+    red[rg][col] = a;
   }
   __syncthreads();
   if (t < EV_NACC) {
     double s = 0.0;
-    if (t == 0 || (t - 1) % EV_MAXK < K)
-      for (int w = 0; w < 16; ++w) s += red[w][t];
+#pragma unroll 8
+    for (int w = 0; w < RG; ++w) s += red[w][t];
     tot[t] = s;
   }
   __syncthreads();
