@@ -33,8 +33,8 @@ FLOP_PER_VOXEL_FWD_BWD = 428160  # conv FLOPs fwd+bwd per voxe
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=2, help="samples per GPU (reference default 2, trainUMIS.py:1360)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -91,6 +91,23 @@ def kernel_probe(batch, size, dtype):
     res["evid_head_loss_fwd"] = (timeit(lambda: ops.evid_loss_fwd(z, True, lab, 0.5, True)), 0.0, vox * (4 * esz + 8 + 16))
     res["evid_head_loss_bwd"] = (timeit(lambda: ops.evid_loss_bwd(z, True, lab, 0.5, scal, one)), 0.0, vox * (4 * esz + 8 + 4 * esz))
     return res
+
+
+def pmc_lookup(name_parts, voxels, dtype):
+    """(HBM bytes per launch, MFMA-pipe busy fraction) of the kernel whose name contains every string of
+    `name_parts`, from profiles/r02_pmc_step.json (counters taken at B=2 x 128^3; bytes scale with the voxels)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_step.json")
+    if dtype != torch.bfloat16 or not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for k, v in kernels.items():
+        if all(p_ in k for p_ in name_parts):
+            return v["hbm_bytes"] * voxels / (2 * 128 ** 3), v["mfma_util"]
+    return None, None
 
 
 def cpu_baseline(steps, size):
@@ -210,15 +227,16 @@ def main():
         # (2.5 PF / 8 TB/s = 312), so the roof that binds it is HBM; the MFMA fraction is reported next to it.
         name = "conv3d_fwd_c16"
         t, flops, alg_bytes = probe[name]
-        # HBM bytes per launch from the PMC passes in profiles/r01_pmc_{fetch,write}_size_march_c16.csv
-        # (B=2, 128^3): FETCH_SIZE 70,937 KB x2 (gfx950 reports half of a wide coalesced read,
-        # MI355X_MICROARCH.md "HBM") + WRITE_SIZE 131,072 KB; scaled linearly with the voxel count.
-        traffic = (2 * 70937.5 + 131072.0) * 1024 * (a.batch * S ** 3) / (2 * 128 ** 3) if dtype == torch.bfloat16 else None
+        # HBM bytes per launch of THIS kernel from the tracked counter passes (profiles/r02_pmc_step.json, made by
+        # tools/pmc_step.sh on the shipped build: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), looked up by
+        # kernel name and scaled with the voxel count; null when the file or the kernel is missing.
+        traffic, pmc_mfma_util = pmc_lookup(("k_conv3_c16_march<8, 32, true, false, false, true, 1>",), a.batch * S ** 3, dtype)
         out["roofline"] = {"kernel": "k_conv3_c16_march<8,32,PRO> (" + name + ")", "bound": "hbm",
                            "achieved": alg_bytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": alg_bytes / t / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                            "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
                            "mfma_achieved_TFLOPs": flops / t / 1e12, "mfma_frac": flops / t / 1e12 / PEAK_BF16_TFLOPS,
+                           "mfma_pipe_busy_frac_pmc": pmc_mfma_util,
                            "all": {k: {"ms": v[0] * 1e3, "TFLOP/s": v[1] / v[0] / 1e12, "GB/s_alg": v[2] / v[0] / 1e9}
                                    for k, v in probe.items()}}
         if world == 1 and not a.no_cpu_baseline:

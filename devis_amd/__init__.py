@@ -1,5 +1,5 @@
 """devis_amd - the DEviS evidential U-Net hot path on MI355X (gfx950) HIP kernels."""
-from .unet3d import Unet                      # noqa: F401
+from .unet3d import Unet, Unetdrop            # noqa: F401
 from .attunet3d import AttUnet                # noqa: F401
 from .vnet3d import VNet                      # noqa: F401
 from .vnet2d import VNet2D                    # noqa: F401

@@ -99,6 +99,7 @@ SIGNATURES = {
     "devis_norm_bwd_finalize_partials": (_I, [_P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devis_norm_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P]),
     "devis_add": (_I, [_P, _P, _P, _I64, _I, _P]),
+    "devis_mul": (_I, [_P, _P, _P, _I64, _I, _P]),
     "devis_maxpool2d_fwd": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "devis_maxpool2d_bwd": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "devis_maxpool2d_bwd_add": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P]),

@@ -112,15 +112,15 @@ class _RunAtt(_Run):
         n, v, c = ops._nvc(g1)
         dskip, dz, part = ops.att_gate_bwd(datt, x, s, st_p)
         coef_p, g[name + ".psi.1.weight"], g[name + ".psi.1.bias"] = ops.norm_bwd_coeffs(
-            part, n, v, 1, P[name + ".psi.1.weight"], st_p[2], st_p[3], 0, True, out=self._o(name + ".psi.1"))
+            part, n, v, 1, P[name + ".psi.1.weight"], st_p[2], st_p[3], 0, 1 if self.training else 2, out=self._o(name + ".psi.1"))
         dpre, mom_g, mom_x = ops.att_psi_bwd(dz, s, coef_p, g1, x1, st_g, st_x, P[name + ".psi.0.weight"],
                                              out=self._o(name + ".psi.0"))
         g[name + ".psi.0.weight"], g[name + ".psi.0.bias"] = self._o(name + ".psi.0")
         dg1, g[name + ".W_g.1.weight"], g[name + ".W_g.1.bias"] = ops.norm_relu_bwd(
-            dpre, g1, None, None, P[name + ".W_g.1.weight"], st_g[2], st_g[3], 0, True, out=self._o(name + ".W_g.1"),
+            dpre, g1, None, None, P[name + ".W_g.1.weight"], st_g[2], st_g[3], 0, 1 if self.training else 2, out=self._o(name + ".W_g.1"),
             partials=mom_g, relu=False)
         dx1, g[name + ".W_x.1.weight"], g[name + ".W_x.1.bias"] = ops.norm_relu_bwd(
-            dpre, x1, None, None, P[name + ".W_x.1.weight"], st_x[2], st_x[3], 0, True, out=self._o(name + ".W_x.1"),
+            dpre, x1, None, None, P[name + ".W_x.1.weight"], st_x[2], st_x[3], 0, 1 if self.training else 2, out=self._o(name + ".W_x.1"),
             partials=mom_x, relu=False)
         g[name + ".W_g.0.weight"], g[name + ".W_g.0.bias"] = self._wg(
             ops.conv_wgrad, gt, None, dg1, G1, P[name + ".W_g.0.weight"].shape, out=self._o(name + ".W_g.0"))

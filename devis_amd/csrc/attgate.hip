@@ -40,10 +40,8 @@ template <> __device__ __forceinline__ void a_store<float>(float* p, const float
   *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
 }
 template <> __device__ __forceinline__ void a_store<bf16>(bf16* p, const float* in) {
-  union { bf16 h[8]; uint4 v; } u;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) u.h[i] = (bf16)in[i];
-  *reinterpret_cast<uint4*>(p) = u.v;
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(in[0], in[1]), pack_bf16x2(in[2], in[3]), pack_bf16x2(in[4], in[5]),
+                                             pack_bf16x2(in[6], in[7]));
 }
 
 #define ATT_VPB 2048          // voxels per block of the thread-per-voxel kernels (8 per thread)

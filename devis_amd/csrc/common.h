@@ -24,6 +24,16 @@ template <typename T> __device__ __forceinline__ void st(T* p, float v) { *p = (
 
 __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// two floats -> two bf16 (round to nearest even) in one dword, low half = a.  The vector conversion compiles to ONE
+// v_cvt_pk_bf16_f32; converting the halves one by one costs four instructions (two converts, a shift, an or).
+typedef __attribute__((ext_vector_type(2))) float devis_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 devis_bf16x2;
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  union { devis_bf16x2 v; unsigned u; } r;
+  r.v = __builtin_convertvector((devis_f32x2){a, b}, devis_bf16x2);
+  return r.u;
+}
+
 // wave64 reductions (DPP/shuffle; no LDS)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

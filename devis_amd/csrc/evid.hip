@@ -142,9 +142,7 @@ __device__ __forceinline__ void store4(float* p, const float* v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ void store4(bf16* p, const float* v) {
-  union { bf16 h[4]; uint2 u; } r;
-  r.h[0] = (bf16)v[0]; r.h[1] = (bf16)v[1]; r.h[2] = (bf16)v[2]; r.h[3] = (bf16)v[3];
-  *reinterpret_cast<uint2*>(p) = r.u;
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
 }
 
 // KT: compile-time class count (4) or 0 for the run-time K <= EV_MAXK path

@@ -14,12 +14,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
-  union { bf16 h[2]; unsigned u; } r;
-  r.h[0] = (bf16)a;
-  r.h[1] = (bf16)b;
-  return r.u;
-}
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) { return pack_bf16x2(a, b); }
 
 // relu(scale * x + shift) on 8 packed bf16 (the fused norm prologue)
 __device__ __forceinline__ uint4 affine_relu8(uint4 v, const float* sc, const float* sh) {

@@ -37,10 +37,8 @@ template <> __device__ __forceinline__ void store_vec<float>(float* p, const flo
   *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
 }
 template <> __device__ __forceinline__ void store_vec<bf16>(bf16* p, const float* in) {
-  union { bf16 h[8]; uint4 v; } u;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) u.h[i] = (bf16)in[i];
-  *reinterpret_cast<uint4*>(p) = u.v;
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(in[0], in[1]), pack_bf16x2(in[2], in[3]), pack_bf16x2(in[4], in[5]),
+                                             pack_bf16x2(in[6], in[7]));
 }
 
 // MODE 0: {sum x, sum x^2};  MODE 1: dy' = dy*[sc*x+sh>0] -> {sum dy', sum dy'*x}
@@ -220,8 +218,9 @@ __global__ void k_norm_bwd_finalize(const double* __restrict__ mom, int64_t N, i
     const double M = (double)N * (double)V;
     const double s1 = gm * m0, sxy = gm * m1;
     const double s2 = r * (sxy - mu * s1);
-    const double B = -r * r * s2 / M;
-    const double Cc = -r * s1 / M - mu * B;
+    // bn == 2: BatchNorm normalising with its RUNNING statistics (eval mode): mean and rstd are constants of x
+    const double B = bn == 2 ? 0.0 : -r * r * s2 / M;
+    const double Cc = bn == 2 ? 0.0 : -r * s1 / M - mu * B;
     for (int64_t n = 0; n < N; ++n) { cA[n * C + c] = (float)(gm * r); cB[n * C + c] = (float)B; cC[n * C + c] = (float)Cc; }
     dg = r * (m1 - mu * m0);
     db = m0;
@@ -378,8 +377,9 @@ k_norm_bwd_finalize_p(const double* __restrict__ partial, int64_t chunks, int64_
     const double M = (double)N * (double)V;
     const double s1 = gm * m0, sxy = gm * m1;
     const double s2 = r * (sxy - mu * s1);
-    const double B = -r * r * s2 / M;
-    const double Cc = -r * s1 / M - mu * B;
+    // bn == 2: BatchNorm normalising with its RUNNING statistics (eval mode): mean and rstd are constants of x
+    const double B = bn == 2 ? 0.0 : -r * r * s2 / M;
+    const double Cc = bn == 2 ? 0.0 : -r * s1 / M - mu * B;
     for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
       cA[n * C + c] = (float)(gm * r); cB[n * C + c] = (float)B; cC[n * C + c] = (float)Cc;
     }
@@ -539,6 +539,14 @@ __global__ void __launch_bounds__(256)
 k_add(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ z, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     st(z + i, ld(a + i) + ld(b + i));
+}
+
+// z = a * b (elementwise): nn.Dropout's `input * noise` with the noise tensor given (Unetdrop, UNet3DZoo.py:352-366)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_mul(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ z, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    st(z + i, ld(a + i) * ld(b + i));
 }
 
 // -------------------------------------------------------------------- maxpool
@@ -861,6 +869,12 @@ int devis_norm_bwd_apply(const void* dy, const void* x, const float* sc, const f
 int devis_add(const void* a, const void* b, void* z, int64_t n, int dtype, void* stream) {
   if (!a || !b || !z || n <= 0) return DEVIS_ERR_BAD_ARG;
   DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_add<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)z, n));
+  return launch_status();
+}
+
+int devis_mul(const void* a, const void* b, void* z, int64_t n, int dtype, void* stream) {
+  if (!a || !b || !z || n <= 0) return DEVIS_ERR_BAD_ARG;
+  DEVIS_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_mul<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)z, n));
   return launch_status();
 }
 

@@ -550,7 +550,8 @@ def _open_gate(n: int, c: int, device):
 
 def norm_bwd_coeffs(partials, n: int, v: int, c: int, gamma: Tensor, mean: Tensor, rstd: Tensor, groups: int,
                     bn: bool, out=None):
-    """Per-chunk moments {sum dy', sum dy'*x} -> (coef[3, n, c] = cA, cB, cC of dx = cA*dy' + cB*x + cC, dgamma, dbeta)."""
+    """Per-chunk moments {sum dy', sum dy'*x} -> (coef[3, n, c] = cA, cB, cC of dx = cA*dy' + cB*x + cC, dgamma, dbeta).
+    bn: False / 0 GroupNorm, True / 1 BatchNorm on batch statistics, 2 BatchNorm on its running statistics (eval)."""
     ws, chunks = partials
     f = dict(dtype=torch.float32, device=gamma.device)
     coef = torch.empty((3, n, c), **f)
@@ -648,6 +649,16 @@ def add(a: Tensor, b: Tensor) -> Tensor:
         raise _lib.DevisError("add: shape/dtype mismatch")
     z = torch.empty_like(a)
     check(_lib.load().devis_add(_p(a), _p(b), _p(z), a.numel(), dt_code(a.dtype), _stream()), "add")
+    return z
+
+
+def mul(a: Tensor, b: Tensor) -> Tensor:
+    """a * b elementwise (dropout with the noise tensor given)."""
+    _need_cuda(a, b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise _lib.DevisError("mul: shape/dtype mismatch")
+    z = torch.empty_like(a)
+    check(_lib.load().devis_mul(_p(a), _p(b), _p(z), a.numel(), dt_code(a.dtype), _stream()), "mul")
     return z
 
 

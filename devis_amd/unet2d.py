@@ -132,13 +132,13 @@ class _Run2d:
         _, name, x1, x2, h1, h2, st1, st2, w0, w3 = self.tape.pop()
         g, P = self.grads, self.P
         dh2, g[name + ".conv.4.weight"], g[name + ".conv.4.bias"] = ops.norm_relu_bwd(
-            dout, h2, st2[0], st2[1], P[name + ".conv.4.weight"], st2[2], st2[3], 0, True)
+            dout, h2, st2[0], st2[1], P[name + ".conv.4.weight"], st2[2], st2[3], 0, 1 if self.training else 2)
         g[name + ".conv.3.weight"], g[name + ".conv.3.bias"] = self._wg(
             ops.conv_wgrad, h1, None, dh2, C3, P[name + ".conv.3.weight"].shape, st1[0], st1[1])
         # this dgrad feeds bn1's backward: its epilogue leaves the two moments that backward needs
         da, _, part = ops.conv_dgrad(dh2, w3, C3, h1.shape, norm=(h1, st1[0], st1[1]))
         dh1, g[name + ".conv.1.weight"], g[name + ".conv.1.bias"] = ops.norm_relu_bwd(
-            da, h1, st1[0], st1[1], P[name + ".conv.1.weight"], st1[2], st1[3], 0, True, partials=part)
+            da, h1, st1[0], st1[1], P[name + ".conv.1.weight"], st1[2], st1[3], 0, 1 if self.training else 2, partials=part)
         g[name + ".conv.0.weight"], g[name + ".conv.0.bias"] = self._wg(
             ops.conv_wgrad, x1, x2, dh1, C3, P[name + ".conv.0.weight"].shape)
         if not need_dx1:

@@ -233,14 +233,15 @@ class _Run:
     def _de_bwd(self, e, dout, partials=None):
         _, name, x, h1, h2, st1, st2, w1, w2 = e
         g, P = self.grads, self.P
+        bnm = 1 if self.training else 2       # eval mode: BatchNorm used its running statistics (constants of x)
         dh2, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
-            dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, True, out=self._o(name + ".bn2"),
+            dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, bnm, out=self._o(name + ".bn2"),
             partials=partials)
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = self._wg(
             ops.conv_wgrad, h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv2"))
         da, _, pt = ops.conv_dgrad(dh2, w2, G3, h1.shape, wd=self._wd(name + ".conv2"), norm=(h1, st1[0], st1[1]))
         dh1, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
-            da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, True, out=self._o(name + ".bn1"),
+            da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, bnm, out=self._o(name + ".bn1"),
             partials=pt)
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = self._wg(
             ops.conv_wgrad, x, None, dh1, G3, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
@@ -367,6 +368,7 @@ class _Unet3dFn(torch.autograd.Function):
         P = dict(zip(names, params))
         taping = any(ctx.needs_input_grad)
         run = model._run_cls(P, dict(model.named_buffers()), model.compute_dtype, model.training, taping, model._packed(P))
+        model._prepare_run(run, x)
         logits = run.forward(ops.to_channels_last(x, model.compute_dtype))
         ctx.run, ctx.names, ctx.model = run, names, model
         ctx.need_dx = ctx.needs_input_grad[1]
@@ -470,6 +472,9 @@ class Unet(nn.Module):
         self._grad_sync = None                       # parallel.FlatGradSync installs itself here
         self.last_flat_grad = None
 
+    def _prepare_run(self, run, x):
+        """Hook: per-call state a backbone hands to its schedule (Unetdrop: the dropout noise)."""
+
     def _grad_views(self, device):
         """One flat fp32 buffer per backward holding every parameter gradient, laid out in the order backward
         produces them (decoder first), plus {name: view}.  The kernels write into the views, autograd hands
@@ -523,3 +528,121 @@ class Unet(nn.Module):
 
 
 Unet._run_cls = _Run
+
+
+# ------------------------------------------------------------ Unetdrop (UNet3DZoo.py:308-372)
+class _RunDrop(_Run):
+    """Schedule of ``Unetdrop``: the U-Net with channel dropout (p = 0.2, ALWAYS on: ``F.dropout3d`` is called with its
+    default training=True, UNet3DZoo.py:30) after InitConv and element dropout (p = 0.5, training mode only) after
+    EnBlock3_2, EnBlock4_3, DeUpCat4 and DeUpCat3 (:352-366); the skip into DeUpCat4 is EnBlock3_1's output (:350,:361).
+    Dropout is ``input * noise`` as ATen evaluates it; the noise tensors come in through ``self.masks``."""
+
+    masks = None
+
+    def _mask(self, h, key):
+        m = self.masks.get(key)
+        if m is None:
+            return h
+        self._push("mul", m)
+        return ops.mul(h, m)
+
+    def _mask_bwd(self, d):
+        if self.tape and self.tape[-1][0] == "mul":
+            d = ops.mul(d, self.tape.pop()[1])
+        return d
+
+    def forward(self, x: Tensor) -> Tensor:
+        h = self.conv("InitConv.conv", x, G3)
+        mi = self.masks["init"]
+        h = ops.affine_act(h, mi, torch.zeros_like(mi), relu=False)       # per-(n, c) noise: moments are taken afterwards
+        s1, _ = self.en_block("EnBlock1", h)
+        h, hs = self.conv("EnDown1.conv", s1, G3S2, True)
+        h, hs = self.en_block("EnBlock2_1", h, hs, True)
+        s2, _ = self.en_block("EnBlock2_2", h, hs)
+        h, hs = self.conv("EnDown2.conv", s2, G3S2, True)
+        s3, hs = self.en_block("EnBlock3_1", h, hs, True)
+        h, _ = self.en_block("EnBlock3_2", s3, hs)
+        h, hs = self.conv("EnDown3.conv", self._mask(h, "d1"), G3S2, True)
+        for i in (1, 2, 3):
+            h, hs = self.en_block("EnBlock4_%d" % i, h, hs, i < 3 or self.masks.get("d2") is None)
+        h, _ = self.en_block("EnBlock4_4", self._mask(h, "d2"), hs if self.masks.get("d2") is None else None)
+        h = self.de_block("DeBlock4", self._mask(self.de_up_cat("DeUpCat4", h, s3), "u1"))
+        h = self.de_block("DeBlock3", self._mask(self.de_up_cat("DeUpCat3", h, s2), "u2"))
+        h = self.de_block("DeBlock2", self.de_up_cat("DeUpCat2", h, s1))
+        return self.conv("endconv", h, G1)
+
+    def backward(self, dlogits: Tensor, need_dx: bool):
+        pop = self.tape.pop
+        self._begin_backward(dlogits.device)
+        d, pt = self._conv_bwd(pop(), dlogits, norm=self._next_norm())           # endconv
+        d = self._de_bwd(pop(), d, pt); d, ds1, pt = self._up_bwd(pop(), d)      # DeBlock2, DeUpCat2
+        d = self._mask_bwd(self._de_bwd(pop(), d, pt)); d, ds2, pt = self._up_bwd(pop(), d)   # DeBlock3, u2, DeUpCat3
+        d = self._mask_bwd(self._de_bwd(pop(), d, pt)); d, ds3, _ = self._up_bwd(pop(), d)    # DeBlock4, u1, DeUpCat4
+        self._bucket_done(0)
+        d = self._mask_bwd(self._en_bwd(pop(), d))                               # EnBlock4_4, d2
+        for _ in range(3):
+            d = self._en_bwd(pop(), d)                                           # EnBlock4_3..1
+        self._bucket_done(1)
+        d = self._mask_bwd(self._conv_bwd(pop(), d))                             # EnDown3, d1
+        d = ops.add(self._en_bwd(pop(), d), ds3)                                 # EnBlock3_2; + the skip gradient
+        d = self._en_bwd(pop(), d)                                               # EnBlock3_1
+        d = self._conv_bwd(pop(), d, skip=ds2)                                   # EnDown2
+        d = self._en_bwd(pop(), d); d = self._en_bwd(pop(), d)
+        d = self._conv_bwd(pop(), d, skip=ds1)                                   # EnDown1
+        d = self._en_bwd(pop(), d)                                               # EnBlock1
+        mi = self.masks["init"]
+        d = ops.affine_act(d, mi, torch.zeros_like(mi), relu=False)
+        d = self._conv_bwd(pop(), d, need_dx)                                    # InitConv
+        self._end_backward()
+        self._bucket_done(2)
+        return d
+
+
+class Unetdrop(Unet):
+    """Drop-in for the reference ``Unetdrop(in_channels, base_channels, num_classes)`` (UNet3DZoo.py:308-372): same
+    parameters and ``state_dict`` keys as ``Unet``.  ``forward(x)`` draws the dropout noise itself (torch's generator
+    of x's device, bernoulli(1 - p) / (1 - p) like ATen's dropout); ``forward(x, masks=...)`` takes it from the
+    caller instead: {'init': (N, C, 1, 1, 1), 'd1', 'd2', 'u1', 'u2': NCDHW or None} - the hook the parity tests use
+    (oracle/devis_oracle.py:unetdrop_masks draws the reference's own noise)."""
+
+    _run_cls = _RunDrop
+    _masks_next = None
+
+    def forward(self, x: Tensor, masks=None) -> Tensor:
+        self._masks_next = masks
+        try:
+            return super().forward(x)
+        finally:
+            self._masks_next = None
+
+    def forward_channels_last(self, x: Tensor, masks=None) -> Tensor:
+        if masks is not None:
+            self._masks_next = masks
+        try:
+            return super().forward_channels_last(x)
+        finally:
+            self._masks_next = None
+
+    def _prepare_run(self, run, x):
+        n, _, d, h, w = x.shape
+        b = self.InitConv.conv.out_channels
+        dev, dt = x.device, self.compute_dtype
+        shapes = {"d1": (n, d // 4, h // 4, w // 4, b * 4), "d2": (n, d // 8, h // 8, w // 8, b * 8),
+                  "u1": (n, d // 4, h // 4, w // 4, b * 4), "u2": (n, d // 2, h // 2, w // 2, b * 2)}
+        given = self._masks_next
+        m = {}
+        if given is None:
+            m["init"] = torch.empty((n, b), dtype=torch.float32, device=dev).bernoulli_(0.8).div_(0.8)
+            for k, shp in shapes.items():
+                m[k] = torch.empty(shp, dtype=dt, device=dev).bernoulli_(0.5).mul_(2.0) if self.training else None
+        else:
+            m["init"] = given["init"].reshape(n, b).to(device=dev, dtype=torch.float32).contiguous()
+            for k, shp in shapes.items():
+                g = given.get(k)
+                m[k] = None if g is None else ops.to_channels_last(g.to(dev), dt)
+                if m[k] is not None and tuple(m[k].shape) != shp:
+                    raise ValueError("Unetdrop mask %r: expected NCDHW of %s" % (k, (shp[0], shp[4]) + shp[1:4]))
+        run.masks = m
+
+
+Unetdrop._run_cls = _RunDrop

@@ -206,7 +206,9 @@ int devis_norm_bwd_moments(const void* dy, const void* x, const float* scale, co
                            int64_t N, int64_t V, int64_t C, int dtype, double* out, void* workspace,
                            size_t workspace_bytes, void* stream);
 /* moments -> dx = cA*dy' + cB*x + cC  coefficients [N][C], and dgamma/dbeta [C].
- * `bn` = 0: GroupNorm with G groups (mean/rstd [N][G]); 1: BatchNorm (mean/rstd [C]). */
+ * `bn` = 0: GroupNorm with G groups (mean/rstd [N][G]); 1: BatchNorm on batch statistics (mean/rstd [C]);
+ * 2: BatchNorm normalising with its running statistics (eval mode: cB = cC = 0, as autograd gives for
+ * F.batch_norm(training=False)). */
 int devis_norm_bwd_finalize(const double* moments, int64_t N, int64_t V, int64_t C, int64_t G, int bn,
                             const float* gamma, const float* mean, const float* rstd, float* cA,
                             float* cB, float* cC, float* dgamma, float* dbeta, void* stream);
@@ -237,6 +239,9 @@ int devis_norm_bwd_apply(const void* dy, const void* x, const float* scale, cons
                          int64_t N, int64_t V, int64_t C, int dtype, void* stream);
 /* z = a + b: elementwise add of two channels-last tensors (skip-gradient accumulation) */
 int devis_add(const void* a, const void* b, void* z, int64_t n_elems, int dtype, void* stream);
+/* z = a * b: nn.Dropout / F.dropout3d as the reference evaluates them, `input * noise` (Unetdrop,
+ * UNet3DZoo.py:30,352,358,362,366), with the noise tensor supplied by the caller; also its backward. */
+int devis_mul(const void* a, const void* b, void* z, int64_t n_elems, int dtype, void* stream);
 
 /* nn.MaxPool2d(2) (UNet2DZoo.py:112-118), floor mode; idx = argmax position 0..3 inside the window */
 int devis_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int64_t N, int64_t H, int64_t W, int64_t C,

@@ -91,6 +91,47 @@ def unet3d_forward(sd: StateDict, x: Tensor, training: bool = True) -> Tensor:
     return _conv(sd, "endconv", h, pad=0)
 
 
+def unetdrop_masks(x_shape, training: bool = True, base: int = 16):
+    """The five dropout masks of one ``Unetdrop.forward`` call, drawn from torch's global generator with the shapes
+    and in the order the reference draws its noise (UNet3DZoo.py:30 ``F.dropout3d(y, 0.2)`` - training=True ALWAYS,
+    also in eval mode - then nn.Dropout(0.5) at :352, :358, :362, :366, which are identity in eval mode).
+    ATen's dropout is ``input * noise`` with noise = bernoulli(1 - p) / (1 - p) (feature dropout: noise of shape
+    (N, C, 1, 1, 1)), so ``dropout(ones)`` IS the noise tensor the reference multiplies by after the same seeding."""
+    n, _, d, h, w = x_shape
+    m = {"init": F.dropout3d(torch.ones((n, base, d, h, w)), 0.2)[:, :, :1, :1, :1].contiguous()}
+    shapes = {"d1": (n, base * 4, d // 4, h // 4, w // 4), "d2": (n, base * 8, d // 8, h // 8, w // 8),
+              "u1": (n, base * 4, d // 4, h // 4, w // 4), "u2": (n, base * 2, d // 2, h // 2, w // 2)}
+    for k in ("d1", "d2", "u1", "u2"):
+        m[k] = F.dropout(torch.ones(shapes[k]), 0.5, training) if training else None
+    return m
+
+
+def unetdrop3d_forward(sd: StateDict, x: Tensor, training: bool = True, masks=None) -> Tensor:
+    """Unetdrop.forward, UNet3DZoo.py:340-372, with the dropout noise passed in (``unetdrop_masks``): channel
+    dropout p = 0.2 after InitConv (:30,:312), element dropout p = 0.5 after EnBlock3_2 (:352), EnBlock4_3 (:358),
+    DeUpCat4 (:362) and DeUpCat3 (:366).  Note :350-361: the skip into DeUpCat4 is the output of EnBlock3_1, not of
+    EnBlock3_2."""
+    if masks is None:
+        masks = unetdrop_masks(x.shape, training, sd["InitConv.conv.weight"].shape[0])
+    mul = lambda t, k: t if masks.get(k) is None else t * masks[k]
+    h = mul(_conv(sd, "InitConv.conv", x), "init")
+    s1 = _en_block(sd, "EnBlock1", h)
+    h = _conv(sd, "EnDown1.conv", s1, stride=2)
+    h = _en_block(sd, "EnBlock2_1", h)
+    s2 = _en_block(sd, "EnBlock2_2", h)
+    h = _conv(sd, "EnDown2.conv", s2, stride=2)
+    s3 = _en_block(sd, "EnBlock3_1", h)
+    h = mul(_en_block(sd, "EnBlock3_2", s3), "d1")
+    h = _conv(sd, "EnDown3.conv", h, stride=2)
+    for i in (1, 2, 3):
+        h = _en_block(sd, "EnBlock4_%d" % i, h)
+    h = _en_block(sd, "EnBlock4_4", mul(h, "d2"))
+    h = _de_block(sd, "DeBlock4", mul(_de_up_cat(sd, "DeUpCat4", h, s3), "u1"), training)
+    h = _de_block(sd, "DeBlock3", mul(_de_up_cat(sd, "DeUpCat3", h, s2), "u2"), training)
+    h = _de_block(sd, "DeBlock2", _de_up_cat(sd, "DeUpCat2", h, s1), training)
+    return _conv(sd, "endconv", h, pad=0)
+
+
 # ----------------------------------------------------------------------------
 # 3D attention U-Net  (models/lib/UNet3DZoo.py:69-115,132-143,167-241)   SURVEY.md §8(f)-1
 # ----------------------------------------------------------------------------

@@ -247,3 +247,32 @@ def test_oracle_vnet2d_train_step(golden, seed):
     assert [tuple(t) for t in log] == want
     k = "block_five.conv.3.weight"
     assert rel_err(sd[k].grad.reshape(-1)[::37], G[pre + "grad_" + k]) < 1e-4
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_oracle_unetdrop_matches_reference_goldens(golden, seed):
+    """oracle.unetdrop3d_forward, fed the dropout noise re-drawn from the same RNG state, against the numbers the REAL
+    reference Unetdrop produced (make_goldens.py asserted bit equality); the product class initialises like it."""
+    from oracle import devis_oracle as O
+    from devis_amd import Unetdrop
+    G = golden("unetdrop")
+    pre = "s%d_" % seed
+    shape = tuple(int(v) for v in G[pre + "shape"])
+    train = bool(int(G[pre + "train"]))
+    torch.manual_seed(seed)
+    net = Unetdrop(4, 16, 4, compute_dtype=torch.float32)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    assert sd_hash(sd) == str(G[pre + "sd_hash"])
+    for k in sd:
+        if sd[k].is_floating_point() and k.split(".")[-1] in ("weight", "bias"):
+            sd[k].requires_grad_(True)
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(5000 + seed))
+    torch.manual_seed(1000 + seed)
+    masks = O.unetdrop_masks(x.shape, train)
+    assert np.array_equal((masks["init"].reshape(shape[0], 16) != 0).numpy(), G[pre + "keep_init"])
+    assert (masks["d1"] is None) == (not train)
+    y = O.unetdrop3d_forward(sd, x, train, masks)
+    y.square().mean().backward()
+    assert torch.equal(y.detach(), torch.from_numpy(G[pre + "logits"]))
+    k = "EnBlock3_2.conv1.weight"
+    assert np.array_equal(sd[k].grad.reshape(-1)[::37].numpy(), G[pre + "grad_" + k])
