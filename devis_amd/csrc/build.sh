@@ -5,8 +5,8 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # packed fp32 VALU ops are off: v_pk_fma_f32 gave run-to-run different low lanes when kernels of another stream
 # shared the CU; none of these kernels is VALU-bound enough to miss them
-# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs (no v_accvgpr_read per result dword in the epilogues,
-# 10-20 fewer registers per kernel: the prologue variants of the marching kernels reach three waves per SIMD)
+# (-mllvm -amdgpu-mfma-vgpr-form was measured: the prologue variant of the 16-channel conv gains 7 %, its residual
+# variant and the head dgrad lose 25 % - not used)
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops"
 mkdir -p build
 pids=()
