@@ -14,6 +14,8 @@
 #include "common.h"
 #include "mfma_common.h"
 
+#include <stdlib.h>
+
 namespace devis {
 
 struct DeepArgs {
@@ -283,7 +285,13 @@ int conv3_deep(const devis_conv_desc* d, const void* x, const void* w, const flo
   if (d->dtype != DEVIS_BF16 || d->C2 != 0 || d->SD != 1 || d->C1 != d->Cout) return DEVIS_ERR_UNSUPPORTED;
   if (d->OD != d->ID || d->OH != d->IH || d->OW != d->IW) return DEVIS_ERR_UNSUPPORTED;
   if (d->N * d->ID * d->IH * d->IW * d->C1 >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
-  if (d->C1 == 128) return launch_deep<128, 2, 4>(d, x, w, bias, sc, sh, res, y, st, plan_chunks, s);
+  if (d->C1 == 128) {
+    // (2, 2, 16) tiles: 75 KB of LDS per block, so TWO blocks share a CU and hide each other's chunk fetches and
+    // barriers (a (2, 4, 16) block owns its CU alone: one wave per SIMD, every L2 round trip exposed)
+    static const bool big = getenv("DEVIS_DEEP128_BIG_TILE") != nullptr;
+    if (big) return launch_deep<128, 2, 4>(d, x, w, bias, sc, sh, res, y, st, plan_chunks, s);
+    return launch_deep<128, 2, 2>(d, x, w, bias, sc, sh, res, y, st, plan_chunks, s);
+  }
   if (d->C1 == 64) return launch_deep<64, 4, 4>(d, x, w, bias, sc, sh, res, y, st, plan_chunks, s);
   return DEVIS_ERR_UNSUPPORTED;
 }

@@ -262,6 +262,30 @@ __device__ __forceinline__ void reduce_chunks(const double* __restrict__ partial
     const int t = threadIdx.x, nw = (int)(blockDim.x >> 6), lane = t & 63, wave = t >> 6;
     const int j = t & (nout - 1), r = t / nout, RT = (int)blockDim.x / nout;
     double* wsum = sm + nn * nout;                     // [nn][nw][nout]
+    if (nn == 2) {
+      // the batch of the BraTS step: both samples' loads are issued before either sum waits (one memory round trip
+      // instead of two; same addends, same order per sample)
+      const double* p0 = partial + (n0 * chunks * C + c0) * 2 + j;
+      const double* p1 = p0 + chunks * C * 2;
+      double a[2][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[0][u] = 0.0; a[1][u] = 0.0; }
+      int64_t k = r;
+      for (; k + 7 * RT < chunks; k += 8 * RT) {
+        double v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v0[u] = p0[(k + u * RT) * st]; v1[u] = p1[(k + u * RT) * st]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[0][u] += v0[u]; a[1][u] += v1[u]; }
+      }
+      for (; k < chunks; k += RT) { const double v0 = p0[k * st], v1 = p1[k * st]; a[0][0] += v0; a[1][0] += v1; }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        double s = ((a[n][0] + a[n][1]) + (a[n][2] + a[n][3])) + ((a[n][4] + a[n][5]) + (a[n][6] + a[n][7]));
+        for (int w = nout; w < 64; w <<= 1) s += __shfl_xor(s, w, 64);
+        if (lane < nout) wsum[(n * nw + wave) * nout + lane] = s;
+      }
+    } else
     for (int n = 0; n < nn; ++n) {
       const double* p = partial + ((n0 + n) * chunks * C + c0) * 2 + j;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
