@@ -78,7 +78,19 @@ def kernel_probe(batch, size, dtype):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e-3
 
-    res["conv3d_fwd_c16"] = (timeit(lambda: ops.conv_fwd(x, None, wp, b, G3, sc, sh)), flops, vox * 16 * esz * 2)
+    # the roofline kernel: launched through the C ABI into a preallocated output, 20 back-to-back launches between the
+    # two events (the Python wrapper's allocation and checks would otherwise sit between launches)
+    import ctypes as C
+    from devis_amd import _lib
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    d = G3.desc(batch, (size, size, size), 16, 0, 16, dtype)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fwd_direct():
+        _lib.check(lib.devis_conv_fwd(C.byref(d), x.data_ptr(), None, wp.data_ptr(), b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                      None, y.data_ptr(), stream), "conv_fwd")
+    res["conv3d_fwd_c16"] = (timeit(fwd_direct, reps=20), flops, vox * 16 * esz * 2)
     res["conv3d_dgrad_c16"] = (timeit(lambda: ops.conv_dgrad(dy, wp, G3, x.shape)), flops, vox * 16 * esz * 2)
     res["conv3d_wgrad_c16"] = (timeit(lambda: ops.conv_wgrad(x, None, dy, G3, w.shape, sc, sh)), flops, vox * 16 * esz * 2)
     # the fused evidential head + loss (north_star's second roofline): channels-last K=4 logits, int64 labels.
@@ -230,8 +242,8 @@ def main():
         # HBM bytes per launch of THIS kernel from the tracked counter passes (profiles/r02_pmc_step.json, made by
         # tools/pmc_step.sh on the shipped build: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), looked up by
         # kernel name and scaled with the voxel count; null when the file or the kernel is missing.
-        traffic, pmc_mfma_util = pmc_lookup(("k_conv3_c16_march<8, 32, true, false, false, true, 1>",), a.batch * S ** 3, dtype)
-        out["roofline"] = {"kernel": "k_conv3_c16_march<8,32,PRO> (" + name + ")", "bound": "hbm",
+        traffic, pmc_mfma_util = pmc_lookup(("k_conv3_c16_march<8, 32, true, false, false, true, 0>",), a.batch * S ** 3, dtype)
+        out["roofline"] = {"kernel": "k_conv3_c16_march<8, 32, true, false, false, true, 0> (" + name + ": 16->16 3x3x3, GroupNorm+ReLU prologue)", "bound": "hbm",
                            "achieved": alg_bytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": alg_bytes / t / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                            "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
