@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdevis_hip.so")
@@ -84,6 +85,7 @@ SIGNATURES = {
     "devis_upcat_supported": (_I, [_I64, _I64, _I64, _I64, _I64, _I]),
     "devis_upcat_prepare": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "devis_upcat_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
+    "devis_upcat_bwd_data": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
     "devis_upcat_grad_combine": (_I, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "devis_moments_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "devis_channel_moments": (_I, [_P, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
@@ -126,10 +128,43 @@ SIGNATURES = {
 _lib = None
 
 
-def load() -> C.CDLL:
+# ---- launch recording (devis_amd/launch_plan.py): while a thread records, load() hands it a proxy that notes every
+# launching call (function, arguments) after making it.  Host-only queries are not noted.
+_recorders = 0                       # threads recording right now (fast path: 0)
+_rec_tls = threading.local()         # .rec: the thread's Recorder
+_NOT_LAUNCHES = ("_bytes", "_chunks", "_supported")
+
+
+class _RecordingLib:
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name.endswith(_NOT_LAUNCHES) or name in ("devis_version", "devis_last_hip_error", "devis_last_hip_error_string"):
+            call = fn
+        else:
+            def call(*args, _fn=fn):
+                rc = _fn(*args)
+                rec = getattr(_rec_tls, "rec", None)
+                if rec is not None and not rec.opaque:
+                    rec.ops.append((_fn, list(args), True))
+                return rc
+        setattr(self, name, call)
+        return call
+
+
+_recording_lib = None
+
+
+def load():
     """Load the HIP library; raise (never fall back) if it is not there."""
-    global _lib
+    global _lib, _recording_lib
     if _lib is not None:
+        if _recorders and getattr(_rec_tls, "rec", None) is not None:
+            if _recording_lib is None:
+                _recording_lib = _RecordingLib(_lib)
+            return _recording_lib
         return _lib
     if not os.path.exists(LIB_PATH):
         raise DevisError(

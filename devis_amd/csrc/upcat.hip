@@ -151,6 +151,158 @@ k_upcat32_fwd(UpcatArgs a) {
   }
 }
 
+// ---- data gradients, one pass over dy (fine resolution):  d prev[v] = W3a^T dy[v],  d t[c] = sum_p M[p]^T dy[fine(c, p)].
+// Same walk and lane layout as the forward kernels; the loads of dy take the place of prev's and the stores of
+// d prev the place of y's.  C = 16: the MFMA B operand is K = 32 = [dy(2j) | dy(2j+1)], so d t takes one MFMA per
+// fine row pair (A = [M[q,0]^T | M[q,1]^T] from `wq`), and d prev one per w parity with the other half of K zero
+// (A = [W3a^T | 0], [0 | W3a^T]).  A wave's two tiles share the 16-byte stores of d t: even lane groups keep tile 0,
+// odd ones tile 1.
+struct UpcatBwdArgs {
+  const bf16* dy; const bf16* w3a_t; const bf16* wq; bf16* dprev; bf16* dt;
+  int N, D, H, W;          // COARSE grid (dt); dy / dprev are (2D, 2H, 2W)
+  int ntw;
+  unsigned ntiles;
+};
+
+__global__ void __launch_bounds__(256)
+k_upcat16_bwd(UpcatBwdArgs a) {
+  constexpr int TPW = 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const bool lo = lq < 2, odd = lq & 1;
+  union U { uint4 u; bf16x8 v; };
+  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+  U ae, ao, at[4];
+  {
+    const uint4 w = *reinterpret_cast<const uint4*>(a.w3a_t + l15 * 16 + odd * 8);
+    ae.u = lo ? w : z4;
+    ao.u = lo ? z4 : w;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) at[q].u = *reinterpret_cast<const uint4*>(a.wq + (l15 * 8 + q * 2 + (lq >> 1)) * 16 + odd * 8);
+  const int D2 = 2 * a.D, H2 = 2 * a.H, W2 = 2 * a.W;
+  (void)D2;
+  uint4 dl[TPW][4];
+  size_t rowb[TPW][4], tb[TPW];
+  bool ok[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const unsigned tile = ((unsigned)blockIdx.x * 4u + (unsigned)wave) * TPW + i;
+    ok[i] = tile < a.ntiles;
+    const unsigned tt = ok[i] ? tile : 0u;
+    const int twi = (int)(tt % (unsigned)a.ntw);
+    unsigned r = tt / (unsigned)a.ntw;
+    const int h = (int)(r % (unsigned)a.H); r /= (unsigned)a.H;
+    const int d = (int)(r % (unsigned)a.D);
+    const int n = (int)(r / (unsigned)a.D);
+    const int w0 = twi * 16;
+    tb[i] = ((((size_t)n * a.D + d) * a.H + h) * a.W + w0 + l15) * 16 + (lq >> 1) * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pd = q >> 1, ph = q & 1;
+      rowb[i][q] = ((((size_t)n * D2 + 2 * d + pd) * H2 + 2 * h + ph) * W2 + 2 * w0 + 2 * l15 + (lq >> 1)) * 16 + odd * 8;
+      dl[i][q] = z4;
+      if (ok[i]) dl[i][q] = *reinterpret_cast<const uint4*>(a.dy + rowb[i][q]);
+    }
+  }
+  unsigned tp[TPW][2];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    f32x4 ct = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      U b;
+      b.u = dl[i][q];
+      const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ae.v, b.v, z, 0, 0, 0);
+      const f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao.v, b.v, z, 0, 0, 0);
+      ct = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[q].v, b.v, ct, 0, 0, 0);
+      // lane: channels lq*4..+3 of d prev at fine voxels 2j (c0) and 2j+1 (c1)
+      const unsigned o00 = pack_bf2(c0[0], c0[1]), o01 = pack_bf2(c0[2], c0[3]);
+      const unsigned o10 = pack_bf2(c1[0], c1[1]), o11 = pack_bf2(c1[2], c1[3]);
+      const unsigned s0 = odd ? o00 : o10, s1 = odd ? o01 : o11;
+      const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16, 64), r1 = (unsigned)__shfl_xor((int)s1, 16, 64);
+      const uint4 out = odd ? make_uint4(r0, r1, o10, o11) : make_uint4(o00, o01, r0, r1);
+      const size_t off = rowb[i][q] - (size_t)((lq >> 1) * 16 + odd * 8) + (size_t)(odd * 16 + (lq >> 1) * 8);
+      if (ok[i]) *reinterpret_cast<uint4*>(a.dprev + off) = out;
+    }
+    tp[i][0] = pack_bf2(ct[0], ct[1]);
+    tp[i][1] = pack_bf2(ct[2], ct[3]);
+  }
+  {
+    // lane: channels lq*4..+3 of d t at coarse voxel j of both tiles; even lq keeps tile 0, odd lq tile 1
+    const unsigned s0 = odd ? tp[0][0] : tp[1][0], s1 = odd ? tp[0][1] : tp[1][1];
+    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16, 64), r1 = (unsigned)__shfl_xor((int)s1, 16, 64);
+    const uint4 out = odd ? make_uint4(r0, r1, tp[1][0], tp[1][1]) : make_uint4(tp[0][0], tp[0][1], r0, r1);
+    if (odd ? ok[1] : ok[0]) *reinterpret_cast<uint4*>(a.dt + (odd ? tb[1] : tb[0])) = out;
+  }
+}
+
+// C = 32: K = 32 channels of one fine voxel per MFMA; two M tiles for d prev (W3a^T, shared by all parities) and two
+// accumulating ones per parity for d t (`wq`).  Lane pairs swap one M tile as in the forward kernel.
+__global__ void __launch_bounds__(256)
+k_upcat32_bwd(UpcatBwdArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const bool odd = lq & 1;
+  union U { uint4 u; bf16x8 v; };
+  U wa[2], wm[8][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    wa[mt].u = *reinterpret_cast<const uint4*>(a.w3a_t + (size_t)(mt * 16 + l15) * 32 + lq * 8);
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      wm[p][mt].u = *reinterpret_cast<const uint4*>(a.wq + (size_t)((mt * 16 + l15) * 8 + p) * 32 + lq * 8);
+  }
+  const unsigned tile = (unsigned)blockIdx.x * 4u + (unsigned)wave;
+  if (tile >= a.ntiles) return;                 // wave-uniform; no barriers in this kernel
+  const int twi = (int)(tile % (unsigned)a.ntw);
+  unsigned r = tile / (unsigned)a.ntw;
+  const int h = (int)(r % (unsigned)a.H); r /= (unsigned)a.H;
+  const int d = (int)(r % (unsigned)a.D);
+  const int n = (int)(r / (unsigned)a.D);
+  const int w0 = twi * 16;
+  const int D2 = 2 * a.D, H2 = 2 * a.H, W2 = 2 * a.W;
+  (void)D2;
+  U pl[8];
+  size_t vox[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
+    vox[p] = (((size_t)n * D2 + 2 * d + pd) * H2 + 2 * h + ph) * W2 + 2 * (w0 + l15) + pw;
+    pl[p].u = *reinterpret_cast<const uint4*>(a.dy + vox[p] * 32 + lq * 8);
+  }
+  const int choff = odd ? 16 + (lq - 1) * 4 : lq * 4;
+  f32x4 ct[2];
+  ct[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  ct[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    unsigned o[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt].v, pl[p].v, z, 0, 0, 0);
+      ct[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[p][mt].v, pl[p].v, ct[mt], 0, 0, 0);
+      o[mt][0] = pack_bf2(c[0], c[1]);
+      o[mt][1] = pack_bf2(c[2], c[3]);
+    }
+    const unsigned s0 = odd ? o[0][0] : o[1][0], s1 = odd ? o[0][1] : o[1][1];
+    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16, 64), r1 = (unsigned)__shfl_xor((int)s1, 16, 64);
+    const uint4 out = odd ? make_uint4(r0, r1, o[1][0], o[1][1]) : make_uint4(o[0][0], o[0][1], r0, r1);
+    *reinterpret_cast<uint4*>(a.dprev + vox[p] * 32 + choff) = out;
+  }
+  {
+    unsigned o[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { o[mt][0] = pack_bf2(ct[mt][0], ct[mt][1]); o[mt][1] = pack_bf2(ct[mt][2], ct[mt][3]); }
+    const unsigned s0 = odd ? o[0][0] : o[1][0], s1 = odd ? o[0][1] : o[1][1];
+    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16, 64), r1 = (unsigned)__shfl_xor((int)s1, 16, 64);
+    const uint4 out = odd ? make_uint4(r0, r1, o[1][0], o[1][1]) : make_uint4(o[0][0], o[0][1], r0, r1);
+    *reinterpret_cast<uint4*>(a.dt + ((((size_t)n * a.D + d) * a.H + h) * a.W + w0 + l15) * 32 + choff) = out;
+  }
+}
+
 // ---- composite weights of one DeUp_Cat (grid = 8 blocks, one per parity p; C <= 64).  fp32 masters in, kernel
 // layouts out:
 //   wc   bf16 [8][C][2C]: parity p = (pd*2+ph)*2+pw; even pw rows = [W3a | M[p]], odd pw rows = [M[p] | W3a]
@@ -314,6 +466,20 @@ int devis_upcat_fwd(const void* prev, const void* t, const void* wc, const float
   constexpr int TPW = 2;
   if (C == 16) hipLaunchKernelGGL((k_upcat16_fwd<TPW>), dim3((unsigned)cdiv(a.ntiles, 4 * TPW)), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_upcat32_fwd, dim3((unsigned)cdiv(a.ntiles, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int devis_upcat_bwd_data(const void* dy, const void* w3a_t, const void* wq, void* dprev, void* dt, int64_t N, int64_t D,
+                         int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+  if (!dy || !w3a_t || !wq || !dprev || !dt) return DEVIS_ERR_BAD_ARG;
+  if (!devis_upcat_supported(N, D, H, W, C, dtype)) return DEVIS_ERR_UNSUPPORTED;
+  UpcatBwdArgs a;
+  a.dy = (const bf16*)dy; a.w3a_t = (const bf16*)w3a_t; a.wq = (const bf16*)wq; a.dprev = (bf16*)dprev; a.dt = (bf16*)dt;
+  a.N = (int)N; a.D = (int)D; a.H = (int)H; a.W = (int)W;
+  a.ntw = (int)(W / 16);
+  a.ntiles = (unsigned)(N * D * H * a.ntw);
+  if (C == 16) hipLaunchKernelGGL(k_upcat16_bwd, dim3((unsigned)cdiv(a.ntiles, 8)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_upcat32_bwd, dim3((unsigned)cdiv(a.ntiles, 4)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -17,6 +17,7 @@ from typing import Dict, List
 import torch
 import torch.nn as nn
 
+from . import launch_plan as _plan
 from . import ops
 from .ops import ConvGeom
 
@@ -29,6 +30,10 @@ G2S2 = ConvGeom((2, 2, 2), (2, 2, 2), (0, 0, 0))
 # DEVIS_NO_UPCAT_FUSE=1: run DeUp_Cat's ConvT and 1x1 as two layers (the path every unsupported shape takes)
 import os as _os
 _UPCAT_FUSE = _os.environ.get("DEVIS_NO_UPCAT_FUSE", "0") != "1"
+# DEVIS_NO_UPCAT_BWD_FUSE=1: its two data gradients from the 1x1 dgrad and the k2-s2 gather kernels (A/B timing)
+_UPCAT_BWD_FUSE = _os.environ.get("DEVIS_NO_UPCAT_BWD_FUSE", "0") != "1"
+# weight-gradient calls handed to the side stream per event (see _Run._wg)
+_WG_BATCH = max(1, int(_os.environ.get("DEVIS_WGRAD_BATCH", "2")))
 
 
 # ------------------------------------------------------------ parameter holders
@@ -178,23 +183,35 @@ class _Run:
         return (self.G[name + a], self.G[name + b])
 
     def _wg(self, fn, *args, **kw):
-        """Run a weight-gradient call.  Nothing on backward's critical path (dgrad -> norm backward -> dgrad ...)
-        reads a weight gradient, so with a side stream they are launched there, behind an event that marks their
-        inputs ready, and fill the CUs the small deep-layer kernels of the main stream leave idle.  The calls
-        allocate nothing (gradient views and workspace are given), so the stream is handed to the kernels
-        directly; their inputs are kept referenced until backward has joined the side stream, so the caching
-        allocator cannot hand their memory out while it is still being read."""
-        side = self.side
-        if side is None:
+        """Run a weight-gradient call (every caller passes its `out` buffers).  Nothing on backward's critical path
+        (dgrad -> norm backward -> dgrad ...) reads a weight gradient, so with a side stream they are launched there,
+        behind an event that marks their inputs ready, and fill the CUs the small deep-layer kernels of the main
+        stream leave idle.  The calls allocate nothing (gradient views and workspace are given), so the stream is
+        handed to the kernels directly; their inputs are kept referenced until backward has joined the side stream,
+        so the caching allocator cannot hand their memory out while it is still being read.  Calls are handed over
+        in groups of `_WG_BATCH`: one event + one stream wait per group (a hipStreamWaitEvent costs the host ~15 us,
+        three kernel launches' worth)."""
+        if self.side is None:
             return fn(*args, **kw)
+        self._pending.append((fn, args, kw))
+        if len(self._pending) >= _WG_BATCH:
+            self._flush_wg()
+        return kw["out"]
+
+    def _flush_wg(self):
+        pend = self._pending
+        if not pend:
+            return
+        self._pending = []
+        side = self.side
         ev = self._events[self._nev % len(self._events)]
         self._nev += 1
-        ev.record()                               # on the main (current) stream: inputs are ready behind it
-        side.wait_event(ev)
+        _plan.call(ev.record, self._main)         # on the main (current) stream: the group's inputs are ready behind it
+        _plan.call(side.wait_event, ev)
         with ops.stream_override(side):
-            out = fn(*args, slot="ws_side", **kw)
-        self._keep.append(args)
-        return out
+            for fn, args, kw in pend:
+                fn(*args, slot="ws_side", **kw)
+                self._keep.append(args)
 
     def _next_norm(self):
         """(h2, scale, shift) of the DeBlock whose backward comes next on the tape: its bn2+ReLU backward needs
@@ -262,8 +279,11 @@ class _Run:
                      P[name + ".conv2.bias"], out=self._o(name + ".conv3") + self._o(name + ".conv2"))
             for k in (".conv3.weight", ".conv3.bias", ".conv2.weight", ".conv2.bias"):
                 g[name + k] = self.G[name + k]
-            dprev = ops.conv_dgrad(dy, m["w3a"], G1, prev.shape, wd=m["w3a_t"])[0]
-            dt = ops.conv_fwd(dy, None, m["wq"], None, G2S2)          # d t = sum_p M[p]^T dy[fine(p)]
+            if _UPCAT_BWD_FUSE:
+                dprev, dt = ops.upcat_bwd_data(dy, m)
+            else:
+                dprev = ops.conv_dgrad(dy, m["w3a"], G1, prev.shape, wd=m["w3a_t"])[0]
+                dt = ops.conv_fwd(dy, None, m["wq"], None, G2S2)      # d t = sum_p M[p]^T dy[fine(p)]
         else:
             _, name, x, prev, t, up, w1, wt, w3 = e
             g[name + ".conv3.weight"], g[name + ".conv3.bias"] = self._wg(
@@ -308,8 +328,9 @@ class _Run:
 
     def _begin_backward(self, device):
         self.side = _side_stream(device)
-        self._keep, self._nev = [], 0
+        self._keep, self._nev, self._pending = [], 0, []
         if self.side is not None:
+            self._main = torch.cuda.current_stream()
             self._events = _side_events(device)
             for v in self.G.values():             # views of one flat buffer: recording one records the block
                 v.record_stream(self.side)
@@ -317,14 +338,16 @@ class _Run:
 
     def _end_backward(self):
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            self._flush_wg()
+            _plan.call(self._main.wait_stream, self.side)
         self._keep = []                           # freed behind the join, on the stream that allocated them
 
     def _bucket_done(self, i):
         if self.sync is not None:
             if self.side is not None:             # the bucket's weight gradients come from the side stream
-                torch.cuda.current_stream().wait_stream(self.side)
-            self.sync.bucket_ready(i)
+                self._flush_wg()
+                _plan.call(self._main.wait_stream, self.side)
+            _plan.call(self.sync.bucket_ready, i)
 
 
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
@@ -360,43 +383,109 @@ def _side_events(device):
 
 
 class _Unet3dFn(torch.autograd.Function):
-    """x (NCDHW fp32) -> channels-last logits; the only autograd node of the backbone."""
+    """x (NCDHW fp32) -> channels-last logits; the only autograd node of the backbone.  A training step at a shape
+    the model has seen is replayed from its launch plan (devis_amd/launch_plan.py) instead of re-running the
+    schedule's Python; the first step at a shape runs eagerly and is recorded."""
 
     @staticmethod
     def forward(ctx, model, x, *params):
         names = model._param_names
-        P = dict(zip(names, params))
         taping = any(ctx.needs_input_grad)
-        run = model._run_cls(P, dict(model.named_buffers()), model.compute_dtype, model.training, taping, model._packed(P))
-        model._prepare_run(run, x)
-        logits = run.forward(ops.to_channels_last(x, model.compute_dtype))
-        ctx.run, ctx.names, ctx.model = run, names, model
+        ctx.names, ctx.model = names, model
         ctx.need_dx = ctx.needs_input_grad[1]
+        plan = model._step_plan(x, params, ctx.need_dx) if taping else None
+        ctx.plan, ctx.run = plan, None
+        if plan is not None and plan.ready():
+            ctx.plan_gen = plan.begin_step(ctx)
+            plan.fwd.run(x=x.data_ptr())
+            return plan.logits.detach()
+        P = dict(zip(names, params))
+
+        def eager():
+            run = model._run_cls(P, model._buffers_by_name(), model.compute_dtype, model.training, taping, model._packed(P))
+            model._prepare_run(run, x)
+            return run, run.forward(ops.to_channels_last(x, model.compute_dtype))
+
+        if plan is None:
+            ctx.run, logits = eager()
+            return logits
+        try:
+            with plan.recording() as rec:
+                ctx.run, logits = eager()
+            plan.fwd = _plan.Segment(rec.ops, {"x": x.data_ptr()})
+        except BaseException:
+            model._drop_plan(plan)
+            raise
+        plan.logits = logits.detach()
+        ctx.plan_gen = plan.begin_step(ctx)
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
+        model, plan = ctx.model, ctx.plan
+        dlogits = dlogits.contiguous()
+        if plan is not None and plan.bwd is not None and ctx.run is None:
+            # replay.  The gradients land in the plan's flat buffer, which the .grad of an earlier step may still alias
+            # (gradient accumulation): its contents are set aside and put back then, and autograd gets a copy to add
+            if ctx.plan_gen != plan.gen:
+                raise RuntimeError("devis_amd Unet: this forward's activations were overwritten by a later forward of "
+                                   "the same launch plan (backward must run before the next forward at this shape)")
+            clean = all(p.grad is None for p in model.parameters())
+            if model._grad_sync is not None and not clean:
+                raise RuntimeError(_DP_GRAD_MSG)
+            held = None if clean else plan.flat.clone()
+            plan.bwd.run(dlogits=dlogits.data_ptr())
+            plan.end_step()
+            flat = plan.flat
+            if held is not None:
+                flat = plan.flat.clone()
+                plan.flat.copy_(held)
+            model.last_flat_grad = plan.flat
+            views = model._views_of(flat)
+            dx = plan.dx.clone() if plan.dx is not None else None
+            return (None, dx) + tuple(views[n] for n in ctx.names)
         run = ctx.run
-        if not run.taping or not run.tape:
+        if run is None or not run.taping or not run.tape:
             raise RuntimeError("devis_amd Unet: backward called twice or without a taped forward")
-        model = ctx.model
-        flat, run.G = model._grad_views(dlogits.device)
-        run.sync = model._grad_sync
-        if run.sync is not None:
-            # the reducer averages the flat buffer in place and .grad must BE that buffer: a .grad left over from an
-            # earlier backward (gradient accumulation, zero_grad(set_to_none=False)) would be summed by autograd with
-            # an un-reduced copy - refuse instead of training on wrong gradients
-            if any(p.grad is not None for p in model.parameters()):
-                raise RuntimeError("data-parallel backward needs .grad = None on every backbone parameter "
-                                   "(call optimizer.zero_grad() / zero_grad(set_to_none=True) first); gradient "
-                                   "accumulation is not supported with the overlapped all-reduce")
-            run.sync.begin(flat, model._bucket_bounds)
-        dx_cl = run.backward(dlogits.contiguous(), ctx.need_dx)
-        dx = ops.from_channels_last(dx_cl) if dx_cl is not None else None
+
+        def eager():
+            flat, run.G = model._grad_views(dlogits.device)
+            run.sync = model._grad_sync
+            if run.sync is not None:
+                # the reducer averages the flat buffer in place and .grad must BE that buffer: a .grad left over from an
+                # earlier backward (gradient accumulation, zero_grad(set_to_none=False)) would be summed by autograd with
+                # an un-reduced copy - refuse instead of training on wrong gradients
+                if any(p.grad is not None for p in model.parameters()):
+                    raise RuntimeError(_DP_GRAD_MSG)
+                _plan.call(run.sync.begin, flat, model._bucket_bounds)
+            dx_cl = run.backward(dlogits, ctx.need_dx)
+            dx = ops.from_channels_last(dx_cl) if dx_cl is not None else None
+            return flat, dx
+
+        recording = plan is not None and plan.bwd is None and plan.fwd is not None and ctx.plan_gen == plan.gen
+        if recording:
+            try:
+                with plan.recording() as rec:
+                    flat, dx = eager()
+                plan.bwd = _plan.Segment(rec.ops, {"dlogits": dlogits.data_ptr()})
+                plan.flat, plan.dx = flat, dx
+                plan.end_step()
+                dx = dx.clone() if dx is not None else None
+            except BaseException:
+                model._drop_plan(plan)
+                raise
+        else:
+            flat, dx = eager()
         grads = tuple(run.G[n] for n in ctx.names)
         run.G = {}
         run.tape, run.grads = [], {}
+        ctx.run = None
         return (None, dx) + grads
+
+
+_DP_GRAD_MSG = ("data-parallel backward needs .grad = None on every backbone parameter "
+                "(call optimizer.zero_grad() / zero_grad(set_to_none=True) first); gradient "
+                "accumulation is not supported with the overlapped all-reduce")
 
 
 class _FromChannelsLast(torch.autograd.Function):
@@ -475,15 +564,70 @@ class Unet(nn.Module):
     def _prepare_run(self, run, x):
         """Hook: per-call state a backbone hands to its schedule (Unetdrop: the dropout noise)."""
 
+    _plan_ok = True             # the schedule issues nothing but C-ABI launches and launch_plan.call()s
+    _grad_on = True
+
+    def _param_list(self):
+        """The parameters in named_parameters() order (module traversal done once: Parameter objects keep their identity
+        through .to() / load_state_dict)."""
+        pl = self.__dict__.get("_param_list_cache")
+        if pl is None:
+            pl = self.__dict__["_param_list_cache"] = [p for _, p in self.named_parameters()]
+        return pl
+
+    def _buffers_by_name(self):
+        """{name: buffer} with the CURRENT buffer tensors (module.to() replaces them), without a module traversal"""
+        slots = self.__dict__.get("_buffer_slots")
+        if slots is None:
+            slots = self.__dict__["_buffer_slots"] = [
+                (m, bn, (mn + "." if mn else "") + bn) for mn, m in self.named_modules() for bn in m._buffers]
+        return {full: m._buffers[bn] for m, bn, full in slots if m._buffers[bn] is not None}
+
+    def _views_of(self, flat):
+        return {n: flat[o:o + k].view(shape) for n, (o, k, shape) in self._grad_layout.items()}
+
+    def _step_plan(self, x, params, need_dx):
+        """The launch plan of a training step at this input shape (None: run eagerly).  Keyed by everything whose
+        address or value the recorded launches carry."""
+        if not (_plan.ENABLED and self._plan_ok and self.training and self._grad_on) or not x.is_cuda or x.dtype != torch.float32 \
+                or not x.is_contiguous() or torch.cuda.is_current_stream_capturing():
+            return None
+        key = (tuple(x.shape), x.device.index, bool(need_dx), self.compute_dtype,
+               torch._C._cuda_getCurrentRawStream(x.device.index), id(self._grad_sync),
+               tuple(p.data_ptr() for p in params), tuple(b.data_ptr() for b in self._buffers_by_name().values()))
+        plans = self.__dict__.setdefault("_plans", {})
+        misses = self.__dict__.setdefault("_plan_misses", {})
+        plan = plans.get(key)
+        if plan is not None:
+            if plan.busy():
+                return None              # a second forward before the first one's backward: eager, on memory of its own
+            if plan.ready():
+                return plan
+            self._drop_plan(plan)        # recorded half-way (its backward never ran): start over, twice at most
+            misses[key] = misses.get(key, 0) + 1
+        if misses.get(key, 0) >= 2:
+            return None                  # forwards without backwards at this shape: not a training loop
+        while len(plans) >= 2:           # each plan owns a step's worth of memory
+            old = next((k for k, p in plans.items() if not p.busy()), None)
+            if old is None:
+                return None
+            del plans[old]
+        plan = plans[key] = _plan.StepPlan(x.device)
+        return plan
+
+    def _drop_plan(self, plan):
+        plans = self.__dict__.get("_plans", {})
+        for k in [k for k, p in plans.items() if p is plan]:
+            del plans[k]
+
     def _grad_views(self, device):
         """One flat fp32 buffer per backward holding every parameter gradient, laid out in the order backward
         produces them (decoder first), plus {name: view}.  The kernels write into the views, autograd hands
         them out as .grad, and the data-parallel reducer all-reduces slices of the flat buffer in place -
         no gather, no copy-back.  `_bucket_bounds` = element ranges of the three overlap buckets."""
         flat = torch.empty((self._grad_total,), dtype=torch.float32, device=device)
-        views = {n: flat[o:o + k].view(shape) for n, (o, k, shape) in self._grad_layout.items()}
         self.last_flat_grad = flat
-        return flat, views
+        return flat, self._views_of(flat)
 
     def _packed(self, P: Dict[str, Tensor]):
         """All conv weights in the kernels' layouts, one launch (rebuilt tables only if a parameter moved)."""
@@ -521,7 +665,8 @@ class Unet(nn.Module):
         if any(s % 8 for s in x.shape[2:]):
             raise ValueError("Unet needs D, H, W divisible by 8 (three stride-2 stages), got %s" % (tuple(x.shape[2:]),))
         ops.require_device(x, first.weight)
-        return _Unet3dFn.apply(self, x, *[p for _, p in self.named_parameters()])
+        self._grad_on = torch.is_grad_enabled()              # (inside the autograd node grad mode is always off)
+        return _Unet3dFn.apply(self, x, *self._param_list())
 
     def forward(self, x: Tensor) -> Tensor:
         return _FromChannelsLast.apply(self.forward_channels_last(x))
@@ -607,6 +752,7 @@ class Unetdrop(Unet):
 
     _run_cls = _RunDrop
     _masks_next = None
+    _plan_ok = False            # the noise is drawn by torch each step: nothing to replay
 
     def forward(self, x: Tensor, masks=None) -> Tensor:
         self._masks_next = masks

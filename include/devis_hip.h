@@ -171,6 +171,8 @@ int devis_convT_wgrad(const devis_convT_desc* d, const void* x, const void* dy, 
  *   wc [8][C][2C] bf16 (forward), bias [C] fp32, w3a [C][1][C] + w3a_t (packed 1x1 weight of the prev half and its
  *   dgrad packing: d prev = devis_conv_dgrad on them), wq [C][8][C] bf16 (k2-s2 conv packing: d t = devis_conv_fwd
  *   of dy with kernel = stride = 2 on it).
+ * devis_upcat_bwd_data: both data gradients (autograd of the lines above) in one pass over dy: dprev (N, 2D, 2H, 2W, C)
+ *   = W3a^T dy and dt (N, D, H, W, C) = sum_p M[p]^T dy[fine(p)], from w3a_t and wq of devis_upcat_prepare.
  * devis_upcat_grad_combine: g = devis_convT_wgrad(t, dy) [C][C][8], dw3a = devis_conv_wgrad(prev, dy) [C][C],
  *   s = its dbias -> dw3 [C][2C], db3, dwt [C][C][8], dbt (the reference's conv3 / conv2 parameter gradients). */
 int devis_upcat_supported(int64_t N, int64_t D, int64_t H, int64_t W, int64_t C, int dtype);
@@ -178,6 +180,8 @@ int devis_upcat_prepare(const float* w3, const float* b3, const float* wt, const
                         float* bias, void* w3a, void* w3a_t, void* wq, void* stream);
 int devis_upcat_fwd(const void* prev, const void* t, const void* wc, const float* bias, void* y, int64_t N, int64_t D,
                     int64_t H, int64_t W, int64_t C, int dtype, void* stream);
+int devis_upcat_bwd_data(const void* dy, const void* w3a_t, const void* wq, void* dprev, void* dt, int64_t N, int64_t D,
+                         int64_t H, int64_t W, int64_t C, int dtype, void* stream);
 int devis_upcat_grad_combine(const float* g, const float* dw3a, const float* s, const float* w3, const float* wt,
                              const float* bt, int64_t C, float* dw3, float* db3, float* dwt, float* dbt, void* stream);
 

@@ -17,7 +17,7 @@ def uncl(t):
     return t.float().permute(0, 4, 1, 2, 3).contiguous().cpu()
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 4, 6, 16), (1, 16, 3, 5, 32), (2, 16, 8, 8, 16), (2, 32, 3, 4, 16), (1, 32, 5, 2, 48)])
+@pytest.mark.parametrize("shape", [(2, 16, 4, 6, 16), (1, 16, 3, 5, 32), (1, 16, 3, 5, 16), (2, 16, 8, 8, 16), (2, 32, 3, 4, 16), (1, 32, 5, 2, 48)])
 def test_upcat_forward_and_gradients(shape):
     from devis_amd import ops
     from devis_amd.unet3d import G1, G2S2
@@ -57,6 +57,12 @@ def test_upcat_forward_and_gradients(shape):
     check(rel_err(dprev, P["prev"].grad), BF16_BAR, "d prev")
     dt = uncl(ops.conv_fwd(dyc, None, m["wq"], None, G2S2))
     check(rel_err(dt, P["t"].grad), BF16_BAR, "d t")
+    # both in one pass over dy (same bf16 weights, fp32 accumulation: only the summation order differs)
+    dprev_f, dt_f = ops.upcat_bwd_data(dyc, m)
+    check(bf16_ulps(uncl(dprev_f), dprev), 1.0, "fused d prev vs the 1x1 dgrad kernel [bf16 ulps]")
+    check(bf16_ulps(uncl(dt_f), dt), 1.0, "fused d t vs the k2-s2 gather kernel [bf16 ulps]")
+    check(rel_err(uncl(dprev_f), P["prev"].grad), BF16_BAR, "fused d prev")
+    check(rel_err(uncl(dt_f), P["t"].grad), BF16_BAR, "fused d t")
     f = dict(dtype=torch.float32, device="cuda")
     gA, s1 = ops.conv_wgrad(cl(prev), None, dyc, G1, (c, c, 1, 1, 1))
     gG, s2 = ops.convT_wgrad(cl(t), dyc, (2, 2, 2), (c, c, 2, 2, 2))
