@@ -160,23 +160,22 @@ _recording_lib = None
 def load():
     """Load the HIP library; raise (never fall back) if it is not there."""
     global _lib, _recording_lib
-    if _lib is not None:
-        if _recorders and getattr(_rec_tls, "rec", None) is not None:
-            if _recording_lib is None:
-                _recording_lib = _RecordingLib(_lib)
-            return _recording_lib
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise DevisError(
-            "libdevis_hip.so not found at %s - build it with devis_amd/csrc/build.sh "
-            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)        # AttributeError if a declared symbol is missing
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DevisError(
+                "libdevis_hip.so not found at %s - build it with devis_amd/csrc/build.sh "
+                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)        # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    if _recorders and getattr(_rec_tls, "rec", None) is not None:
+        if _recording_lib is None:
+            _recording_lib = _RecordingLib(_lib)
+        return _recording_lib
+    return _lib
 
 
 def check(rc: int, what: str) -> None:

@@ -49,7 +49,11 @@ def test_replayed_steps_equal_eager_steps(model_name):
     l0, sd0, p0 = _train(5, False, model_name=model_name)
     l1, sd1, p1 = _train(5, True, model_name=model_name)
     assert not p0 and len(p1) == 1 and next(iter(p1.values())).ready()
-    assert next(iter(p1.values())).gen == 5                 # one recorded step + four replays
+    plan = next(iter(p1.values()))
+    assert plan.gen == 5                                    # one recorded step + four replays
+    # the launches every step must repeat are in the recording (the weight packing was once lost to a load-order bug)
+    fwd = {getattr(fn, "__name__", "") for fn, _, _ in plan.fwd.ops}
+    assert {"devis_pack_weights_batch", "devis_ncx_to_nxc", "devis_conv_fwd_stats"} <= fwd, fwd
     assert l0 == l1, (l0, l1)
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
