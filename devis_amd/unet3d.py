@@ -34,6 +34,10 @@ _UPCAT_FUSE = _os.environ.get("DEVIS_NO_UPCAT_FUSE", "0") != "1"
 _UPCAT_BWD_FUSE = _os.environ.get("DEVIS_NO_UPCAT_BWD_FUSE", "0") != "1"
 # weight-gradient calls handed to the side stream per event (see _Run._wg)
 _WG_BATCH = max(1, int(_os.environ.get("DEVIS_WGRAD_BATCH", "2")))
+# DEVIS_WGRAD_LAG = "a:b": a weight-gradient call on tensors of >= _WG_BIG elements (the full-resolution layers) is
+# handed to the side stream `a` schedule blocks after the one that issued it, the others `b` blocks after (_Run._tick)
+_WG_LAG = tuple(int(v) for v in _os.environ.get("DEVIS_WGRAD_LAG", "0:1").split(":"))
+_WG_BIG = 1 << 24
 
 
 # ------------------------------------------------------------ parameter holders
@@ -193,10 +197,28 @@ class _Run:
         three kernel launches' worth)."""
         if self.side is None:
             return fn(*args, **kw)
+        big = any(isinstance(a, Tensor) and a.numel() >= _WG_BIG for a in args)
+        lag = (_WG_LAG[0] if big else _WG_LAG[1]) if self._lagged else 0
+        due = max(self._blk + lag, self._last_due)          # never overtakes an earlier call
+        self._last_due = due
+        if due > self._blk:
+            self._held.append((due, fn, args, kw))
+            return kw["out"]
         self._pending.append((fn, args, kw))
         if len(self._pending) >= _WG_BATCH:
             self._flush_wg()
         return kw["out"]
+
+    def _tick(self, final=False):
+        """A block of the backward schedule is done (drivers that call this set `_lagged`): hand over the held
+        weight-gradient calls that are due; all of them with `final`."""
+        self._blk += 1
+        if self._held:
+            n = len(self._held) if final else next((i for i, h in enumerate(self._held) if h[0] > self._blk), len(self._held))
+            if n:
+                self._pending += [h[1:] for h in self._held[:n]]
+                self._held = self._held[n:]
+                self._flush_wg()
 
     def _flush_wg(self):
         pend = self._pending
@@ -307,20 +329,22 @@ class _Run:
         pop = t.pop
         self._begin_backward(dlogits.device)
         e = pop()
-        d, pt = self._conv_bwd(e, dlogits, norm=self._next_norm())    # endconv (+ moments for DeBlock2.bn2)
-        d = self._de_bwd(pop(), d, pt); d, ds1, pt = self._up_bwd(pop(), d)   # DeBlock2, DeUpCat2
-        d = self._de_bwd(pop(), d, pt); d, ds2, pt = self._up_bwd(pop(), d)   # DeBlock3, DeUpCat3
-        d = self._de_bwd(pop(), d, pt); d, ds3, _ = self._up_bwd(pop(), d)    # DeBlock4, DeUpCat4
+        tick = self._tick                                    # block boundaries: the clock of the weight-gradient lag
+        self._lagged = True
+        d, pt = self._conv_bwd(e, dlogits, norm=self._next_norm()); tick()    # endconv (+ moments for DeBlock2.bn2)
+        d = self._de_bwd(pop(), d, pt); tick(); d, ds1, pt = self._up_bwd(pop(), d); tick()   # DeBlock2, DeUpCat2
+        d = self._de_bwd(pop(), d, pt); tick(); d, ds2, pt = self._up_bwd(pop(), d); tick()   # DeBlock3, DeUpCat3
+        d = self._de_bwd(pop(), d, pt); tick(); d, ds3, _ = self._up_bwd(pop(), d); tick()    # DeBlock4, DeUpCat4
         self._bucket_done(0)                                     # every decoder gradient is final
         for _ in range(4):
-            d = self._en_bwd(pop(), d)                           # EnBlock4_4..1
+            d = self._en_bwd(pop(), d); tick()                   # EnBlock4_4..1
         self._bucket_done(1)                                     # the 128-channel stage (74 % of the parameters)
-        d = self._conv_bwd(pop(), d, skip=ds3)               # EnDown3 (+ skip gradient)
-        d = self._en_bwd(pop(), d); d = self._en_bwd(pop(), d)
-        d = self._conv_bwd(pop(), d, skip=ds2)               # EnDown2
-        d = self._en_bwd(pop(), d); d = self._en_bwd(pop(), d)
-        d = self._conv_bwd(pop(), d, skip=ds1)               # EnDown1
-        d = self._en_bwd(pop(), d)                               # EnBlock1
+        d = self._conv_bwd(pop(), d, skip=ds3); tick()           # EnDown3 (+ skip gradient)
+        d = self._en_bwd(pop(), d); tick(); d = self._en_bwd(pop(), d); tick()
+        d = self._conv_bwd(pop(), d, skip=ds2); tick()           # EnDown2
+        d = self._en_bwd(pop(), d); tick(); d = self._en_bwd(pop(), d); tick()
+        d = self._conv_bwd(pop(), d, skip=ds1); tick()           # EnDown1
+        d = self._en_bwd(pop(), d); tick()                       # EnBlock1
         d = self._conv_bwd(pop(), d, need_dx)                    # InitConv
         self._end_backward()
         self._bucket_done(2)
@@ -328,7 +352,7 @@ class _Run:
 
     def _begin_backward(self, device):
         self.side = _side_stream(device)
-        self._keep, self._nev, self._pending = [], 0, []
+        self._keep, self._nev, self._pending, self._held, self._blk, self._last_due, self._lagged = [], 0, [], [], 0, 0, False
         if self.side is not None:
             self._main = torch.cuda.current_stream()
             self._events = _side_events(device)
@@ -338,6 +362,7 @@ class _Run:
 
     def _end_backward(self):
         if self.side is not None:
+            self._tick(final=True)
             self._flush_wg()
             _plan.call(self._main.wait_stream, self.side)
         self._keep = []                           # freed behind the join, on the stream that allocated them
@@ -345,6 +370,7 @@ class _Run:
     def _bucket_done(self, i):
         if self.sync is not None:
             if self.side is not None:             # the bucket's weight gradients come from the side stream
+                self._tick(final=True)
                 self._flush_wg()
                 _plan.call(self._main.wait_stream, self.side)
             _plan.call(self.sync.bucket_ready, i)
