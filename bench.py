@@ -210,6 +210,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    host_dt = time.perf_counter() - t0         # the host has enqueued every step; the GPU may still be working
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -229,6 +230,9 @@ def main():
                                "B=%d/GPU x 4x%d^3, K=4, epoch 25 (lambda 0.5), Adam+L2" % (a.batch, S),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world},
         "final_loss": final_loss,
+        # host time to ENQUEUE a step (no sync inside the timed region): below ms_per_step = the GPU is the limit
+        "host_enqueue_ms_per_step": host_dt / a.steps * 1e3,
+        "launch_plan": bool(getattr(getattr(model, "backbone", None), "_plans", None)),
         "conv_mfma_frac_of_step": FLOP_PER_VOXEL_FWD_BWD * (vox / dt) / world / (PEAK_BF16_TFLOPS * 1e12),
     }
     if rank == 0:

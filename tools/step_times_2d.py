@@ -32,7 +32,9 @@ for _ in range(3):
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     l = step()
+t_host = time.perf_counter() - t0            # the host is done enqueueing; what is left is the GPU's backlog
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+print("host enqueue %.2f ms/step; GPU backlog at the end %.2f ms" % (t_host / a.steps * 1e3, (dt * a.steps - t_host) * 1e3))
 px = a.batch * a.size * a.size
 print("Unet2D(1,2) B=%d %dx%d %s: %.2f ms/step, %.1f M px/s, %.1f TFLOP/s, loss %.7f"
       % (a.batch, a.size, a.size, a.dtype, dt * 1e3, px / dt / 1e6, 3 * 367296 * px / dt / 1e12, l.item()))
