@@ -332,6 +332,9 @@ int conv3_deep2(const devis_conv_desc*, const void*, const void*, const float*, 
 int conv3_c32_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
                     const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
 
+int conv3_s2_c16_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                       const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
+
 static bool is_3x3x3(const devis_conv_desc* d) {
   return d->KD == 3 && d->KH == 3 && d->KW == 3 && d->PD == 1 && d->PH == 1 && d->PW == 1 && d->SD == d->SH && d->SH == d->SW;
 }
@@ -369,6 +372,10 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
     // 32 -> 64: the (2,4,16) tile re-reads less halo than (2,2,16): 36 vs 41 us at 64^3 (tools/time_s2_fwd.py);
     // for 16 -> 32 the larger (4,4,16) tile was measured at 145 vs 86 us (one block per CU) and is not built
     static const bool small32 = getenv("DEVIS_S2_SMALL_TILE") != nullptr;
+    // 16 -> 32 (EnDown1): plane march (conv_s2_march.hip); DEVIS_NO_S2_MARCH=1 keeps the tile kernel (A/B runs)
+    static const bool no_s2_march = getenv("DEVIS_NO_S2_MARCH") != nullptr;
+    if (!no_s2_march && ci == 16 && co == 32 && !sc && !res && !(st && st->mode == 2))
+      return conv3_s2_c16_march(d, x1, w, bias, y, st, plan_chunks, s);
     if (ci == 16 && co == 32) return CONV3(16, 32, 2, 4, 16, 2, 1);
     if (ci == 32 && co == 64 && !small32) return CONV3(32, 64, 2, 4, 16, 2, 1);
     if (ci == 32 && co == 64) return CONV3(32, 64, 2, 2, 16, 2, 1);
