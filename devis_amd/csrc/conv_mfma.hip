@@ -374,7 +374,7 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
     static const bool small32 = getenv("DEVIS_S2_SMALL_TILE") != nullptr;
     // 16 -> 32 (EnDown1): plane march (conv_s2_march.hip); DEVIS_NO_S2_MARCH=1 keeps the tile kernel (A/B runs)
     static const bool no_s2_march = getenv("DEVIS_NO_S2_MARCH") != nullptr;
-    if (!no_s2_march && ci == 16 && co == 32 && !sc && !res && !(st && st->mode == 2))
+    if (!no_s2_march && ((ci == 16 && co == 32) || (ci == 32 && co == 64)) && !sc && !res && !(st && st->mode == 2))
       return conv3_s2_c16_march(d, x1, w, bias, y, st, plan_chunks, s);
     if (ci == 16 && co == 32) return CONV3(16, 32, 2, 4, 16, 2, 1);
     if (ci == 32 && co == 64 && !small32) return CONV3(32, 64, 2, 4, 16, 2, 1);

@@ -19,9 +19,9 @@ namespace devis {
 
 struct S2MarchArgs {
   const bf16* x;      // [N][ID][IH][IW][16]
-  const bf16* w;      // [32][27][16]
-  const float* bias;  // [32] or null
-  bf16* y;            // [N][OD][OH][OW][32]
+  const bf16* w;      // [Cout][27][Cin]
+  const float* bias;  // [Cout] or null
+  bf16* y;            // [N][OD][OH][OW][Cout]
   int N, ID, IH, IW, OD, OH, OW;
   int nth, ntw, ndc, DL;
   StatsArgs st;
@@ -220,18 +220,198 @@ k_conv3_s2_c16_march(S2MarchArgs a) {
   }
 }
 
-// 3x3x3, stride 2, pad 1, 16 -> 32 channels, bf16, no prologue, no residual; statistics mode 0 or 1.
+// ---- 32 -> 64 channels (EnDown2).  K = one tap x 32 ci per MFMA; the four waves split the 64 couts (16 each, 27 A
+// fragments = 108 VGPRs) and every wave reads all four N tiles of the (4 x 16) output tile: one ds_read_b128 per MFMA.
+// Voxels are 64 bytes in LDS, their four 16-byte pieces XOR-swizzled by the voxel index (conflict-free b128 reads).
+template <bool FULL, int STATS>
+__global__ void __launch_bounds__(256)       // ~300 VGPRs: one block per CU, which is all a 2 x 32^3 output gives anyway
+k_conv3_s2_c32_march(S2MarchArgs a) {
+  constexpr int TH = 4, TW = 16;
+  constexpr int HH = 2 * TH + 1, HW = 2 * TW + 1, HP = HH * HW;     // 9 x 33 = 297 voxels
+  constexpr int NPT = (HP * 4 + 255) / 256;                        // 5 sixteen-byte pieces per thread per plane
+  constexpr int PLB = NPT * 256 * 16;                              // 20 KB per LDS plane
+  constexpr int R = 3;
+  constexpr int NT = TH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  int tile;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int twi = tile % a.ntw;
+  const int thi = (tile / a.ntw) % a.nth;
+  const int dci = (tile / (a.ntw * a.nth)) % a.ndc;
+  const int n = tile / (a.ntw * a.nth * a.ndc);
+  const int oh0 = thi * TH, ow0 = twi * TW;
+  const int d0 = dci * a.DL;
+  const int d1 = min(d0 + a.DL, a.OD);
+  const size_t iplane = (size_t)a.IH * a.IW, oplane = (size_t)a.OH * a.OW;
+
+  bf16x8 af[27];
+  {
+    const bf16* wrow = a.w + (size_t)(wave * 16 + l15) * 27 * 32 + lq * 8;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) af[t] = *reinterpret_cast<const bf16x8*>(wrow + t * 32);
+  }
+
+  unsigned goff[NPT], loff[NPT];
+  bool ok[NPT];
+  const int piece = tid & 3;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int i = tid + k * 256;
+    const int u = i >> 2;
+    const int hh = u / HW, hw = u - hh * HW;
+    const int ih = 2 * oh0 - 1 + hh, iw = 2 * ow0 - 1 + hw;
+    ok[k] = i < HP * 4 && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW;
+    goff[k] = ok[k] ? (unsigned)((ih * a.IW + iw) * 32 + piece * 8) : 0u;
+    const int ul = hh * HW + (hw & 1) * (TW + 1) + (hw >> 1);      // [row][col parity][col/2]
+    loff[k] = i < HP * 4 ? (unsigned)(ul * 64 + ((piece ^ ((ul >> 1) & 3)) << 4)) : (unsigned)(i * 16);
+  }
+
+  auto load_plane = [&](int id, uint4 (&rg)[NPT]) {
+    const int idc = min(max(id, 0), a.ID - 1);
+    const bf16* xp = a.x + ((size_t)n * a.ID + idc) * iplane * 32;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) rg[k] = *reinterpret_cast<const uint4*>(xp + goff[k]);
+  };
+  auto store_plane = [&](int id, int slot, uint4 (&rg)[NPT]) {
+    const bool pin = id >= 0 && id < a.ID;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      uint4 v = rg[k];
+      const bool keep = pin && ok[k];
+      v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+      *reinterpret_cast<uint4*>(smem + slot * PLB + loff[k]) = v;
+    }
+  };
+  {
+    uint4 r0[NPT], r1[NPT], r2[NPT];
+    load_plane(2 * d0 - 1, r0);
+    load_plane(2 * d0, r1);
+    load_plane(2 * d0 + 1, r2);
+    store_plane(2 * d0 - 1, 0, r0);
+    store_plane(2 * d0, 1, r1);
+    store_plane(2 * d0 + 1, 2, r2);
+  }
+  __syncthreads();
+
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + wave * 16 + lq * 4);
+  unsigned ooff[NT];
+  bool oin[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int oh = oh0 + j, ow = ow0 + l15;
+    oin[j] = FULL || (oh < a.OH && ow < a.OW);
+    ooff[j] = oin[j] ? (unsigned)((oh * a.OW + ow) * 64 + wave * 16 + lq * 4) : 0u;
+  }
+  float f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* nosc = nullptr;
+
+  const int np = d1 - d0;
+  int s0 = 0;
+  for (int it = 0; it < np; ++it) {
+    const int od = d0 + it;
+    uint4 preA[NPT], preB[NPT];
+    load_plane(2 * od + 2, preA);
+    load_plane(2 * od + 3, preB);
+    __builtin_amdgcn_sched_barrier(0);
+
+    int sb[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) { int s = s0 + kd; s = s >= R ? s - R : s; sb[kd] = s * PLB; }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // voxel of (output row j, output col l15) at tap (kh, kw): row 2j + kh, parity-split column
+    auto read_b = [&](int t, bf16x8 (&b)[NT]) {
+      const int kh = (t / 3) % 3, kw = t % 3;
+      const char* p = smem + sb[t / 9];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int ul = (2 * j + kh) * HW + (kw == 1 ? TW + 1 : (kw == 2 ? 1 : 0)) + l15;
+        b[j] = *reinterpret_cast<const bf16x8*>(p + ul * 64 + ((lq ^ ((ul >> 1) & 3)) << 4));
+      }
+    };
+    bf16x8 bA[NT], bB[NT];
+    read_b(0, bA);
+#define S2_INTERLEAVE                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < NT; ++i_) {       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+  }
+#pragma unroll
+    for (int t = 0; t < 27; t += 2) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bA[j], acc[j], 0, 0, 0);
+      if (t + 1 < 27) {
+        read_b(t + 1, bB);
+        S2_INTERLEAVE
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t + 1], bB[j], acc[j], 0, 0, 0);
+        read_b(t + 2, bA);
+        S2_INTERLEAVE
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef S2_INTERLEAVE
+
+    bf16* yp = a.y + ((size_t)n * a.OD + od) * oplane * 64;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      uint2 o;
+      o.x = pack_bf2(acc[j][0] + bv.x, acc[j][1] + bv.y);
+      o.y = pack_bf2(acc[j][2] + bv.z, acc[j][3] + bv.w);
+      if (FULL || oin[j]) *reinterpret_cast<uint2*>(yp + ooff[j]) = o;
+      if (STATS && (FULL || oin[j])) stats_accum<STATS>(o, o, nosc, nosc, f0, f1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    int s1 = s0 + 1; s1 = s1 >= R ? s1 - R : s1;
+    __syncthreads();
+    store_plane(2 * od + 2, s0, preA);
+    store_plane(2 * od + 3, s1, preB);
+    __syncthreads();
+    s0 = s0 + 2 >= R ? s0 + 2 - R : s0 + 2;
+  }
+  if (STATS) {
+    // each wave owns its 16 channels: the 16 lanes that share them add up in fp64 (fixed xor tree), no LDS pass
+    const int chunk = tile % (a.ntw * a.nth * a.ndc);
+    double* pout = a.st.partial + ((size_t)n * a.st.chunks + chunk) * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double sa = (double)f0[j], sbq = (double)f1[j];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { sa += __shfl_xor(sa, o, 64); sbq += __shfl_xor(sbq, o, 64); }
+      if (l15 == 0) {
+        pout[(wave * 16 + lq * 4 + j) * 2 + 0] = sa;
+        pout[(wave * 16 + lq * 4 + j) * 2 + 1] = sbq;
+      }
+    }
+  }
+}
+
+// 3x3x3, stride 2, pad 1, 16 -> 32 or 32 -> 64 channels, bf16, no prologue, no residual; statistics mode 0 or 1.
 // plan_chunks != null: only report the statistics chunks per sample this launch would leave.
 int conv3_s2_c16_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
                        const StatsArgs* st, int64_t* plan_chunks, hipStream_t s) {
-  if (d->dtype != DEVIS_BF16 || d->C1 != 16 || d->C2 != 0 || d->Cout != 32 || d->SD != 2) return DEVIS_ERR_UNSUPPORTED;
-  if (d->IH * d->IW * 16 >= (int64_t)1 << 31 || d->OH * d->OW * 32 >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
+  const bool c16 = d->C1 == 16 && d->Cout == 32, c32 = d->C1 == 32 && d->Cout == 64;
+  if (d->dtype != DEVIS_BF16 || !(c16 || c32) || d->C2 != 0 || d->SD != 2) return DEVIS_ERR_UNSUPPORTED;
+  if (d->IH * d->IW * d->C1 >= (int64_t)1 << 31 || d->OH * d->OW * d->Cout >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
   if (st && st->mode == 2) return DEVIS_ERR_UNSUPPORTED;
+  const int TH = c16 ? 8 : 4;
   S2MarchArgs a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.y = (bf16*)y;
   a.N = (int)d->N; a.ID = (int)d->ID; a.IH = (int)d->IH; a.IW = (int)d->IW;
   a.OD = (int)d->OD; a.OH = (int)d->OH; a.OW = (int)d->OW;
-  a.nth = (int)cdiv(a.OH, 8); a.ntw = (int)cdiv(a.OW, 16);
+  a.nth = (int)cdiv(a.OH, TH); a.ntw = (int)cdiv(a.OW, 16);
   // D chunk: about two blocks per CU; each chunk re-reads one input halo plane
   int dl = 32;
   const int64_t cols = (int64_t)a.N * a.nth * a.ntw;
@@ -245,17 +425,28 @@ int conv3_s2_c16_march(const devis_conv_desc* d, const void* x, const void* w, c
   const int mode = st ? st->mode : 0;
   if (mode) {
     a.st = *st;
-    if (a.st.chunks != a.ndc * a.nth * a.ntw || a.st.C != 32) return DEVIS_ERR_BAD_ARG;
+    if (a.st.chunks != a.ndc * a.nth * a.ntw || a.st.C != d->Cout) return DEVIS_ERR_BAD_ARG;
   }
-  constexpr int LDS = 3 * (((17 * 33 * 2 + 255) / 256) * 256 * 16);
   const dim3 grid((unsigned)tiles);
-  const bool full = a.OH % 8 == 0 && a.OW % 16 == 0;
-  if (mode) {
-    if (full) hipLaunchKernelGGL((k_conv3_s2_c16_march<true, 1>), grid, dim3(256), LDS, s, a);
-    else hipLaunchKernelGGL((k_conv3_s2_c16_march<false, 1>), grid, dim3(256), LDS, s, a);
+  const bool full = a.OH % TH == 0 && a.OW % 16 == 0;
+  if (c16) {
+    constexpr int LDS = 3 * (((17 * 33 * 2 + 255) / 256) * 256 * 16);
+    if (mode) {
+      if (full) hipLaunchKernelGGL((k_conv3_s2_c16_march<true, 1>), grid, dim3(256), LDS, s, a);
+      else hipLaunchKernelGGL((k_conv3_s2_c16_march<false, 1>), grid, dim3(256), LDS, s, a);
+    } else {
+      if (full) hipLaunchKernelGGL((k_conv3_s2_c16_march<true, 0>), grid, dim3(256), LDS, s, a);
+      else hipLaunchKernelGGL((k_conv3_s2_c16_march<false, 0>), grid, dim3(256), LDS, s, a);
+    }
   } else {
-    if (full) hipLaunchKernelGGL((k_conv3_s2_c16_march<true, 0>), grid, dim3(256), LDS, s, a);
-    else hipLaunchKernelGGL((k_conv3_s2_c16_march<false, 0>), grid, dim3(256), LDS, s, a);
+    constexpr int LDS = 3 * (((9 * 33 * 4 + 255) / 256) * 256 * 16);
+    if (mode) {
+      if (full) hipLaunchKernelGGL((k_conv3_s2_c32_march<true, 1>), grid, dim3(256), LDS, s, a);
+      else hipLaunchKernelGGL((k_conv3_s2_c32_march<false, 1>), grid, dim3(256), LDS, s, a);
+    } else {
+      if (full) hipLaunchKernelGGL((k_conv3_s2_c32_march<true, 0>), grid, dim3(256), LDS, s, a);
+      else hipLaunchKernelGGL((k_conv3_s2_c32_march<false, 0>), grid, dim3(256), LDS, s, a);
+    }
   }
   return launch_status();
 }

@@ -57,6 +57,7 @@ CONV_CASES = [
     (1, 64, 0, 128, (4, 8, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (1, 16, 0, 32, (5, 7, 9), (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # odd sizes: ragged parity classes in the dgrad
     (2, 16, 0, 32, (40, 18, 36), (3, 3, 3), (2, 2, 2), (1, 1, 1)),    # stride-2 plane march: five D chunks, ragged tiles
+    (2, 32, 0, 64, (22, 14, 40), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (1, 32, 0, 64, (6, 10, 36), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     # 1x1 layers (gather-GEMM kernels in bf16): DeUpCat conv1 / conv3 (virtual concat) / endconv shapes
     (1, 128, 0, 64, (4, 4, 16), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
@@ -317,6 +318,7 @@ STATS_CASES = [
     (1, 128, 128, (4, 4, 16), 1),    # deep 128
     (1, 16, 32, (8, 8, 32), 2),      # stride-2 (EnDown) variants
     (2, 16, 32, (24, 20, 36), 2),    # stride-2 plane march: several D chunks, ragged tiles
+    (2, 32, 64, (18, 12, 40), 2),
     (2, 32, 64, (8, 8, 16), 2),
     (1, 64, 128, (4, 8, 16), 2),
 ]
