@@ -257,6 +257,9 @@ static int launch_wgrad(const devis_conv_desc* d, const void* x, const float* sc
   return launch_wgrad_reduce(a.part, a.bpart, gx, Cout, Cin, cin_real, dw, dbias, s);
 }
 
+int wgrad3_s2_c16_march(const devis_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, void* ws,
+                        size_t ws_bytes, hipStream_t s, bool query, size_t* need);
+
 static int wgrad_dispatch(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,
                           float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t s, bool query, size_t* need) {
   if (d->dtype != DEVIS_BF16 || d->C2 != 0) return DEVIS_ERR_UNSUPPORTED;
@@ -285,6 +288,20 @@ static int wgrad_dispatch(const devis_conv_desc* d, const void* x, const float* 
     if (ci == 16 && co == 16) WG(16, 16, 4, 4, 1, false);
     if (ci % 32 == 0 && co % 32 == 0 && ci <= 128 && co <= 128) WG(32, 32, 4, 4, 1, false);
   } else if (st == 2) {
+    // 16 -> 32 without a prologue (EnDown1): plane march (conv_wgrad_s2_march.hip); DEVIS_NO_S2_MARCH=1: the tile kernel.
+    // A query sizes the workspace for both (the prologue variant stays on the tile kernel).
+    static const bool no_s2_march = getenv("DEVIS_NO_S2_MARCH") != nullptr;
+    if (!no_s2_march && ci == 16 && co == 32 && (query || !sc)) {
+      const int rc = wgrad3_s2_c16_march(d, x, dy, dw, dbias, ws, ws_bytes, s, query, need);
+      if (!query && rc != DEVIS_ERR_UNSUPPORTED) return rc;
+      if (query) {
+        size_t other = 0;
+        const int rc2 = launch_wgrad<16, 32, 2, 2, 2, false>(d, x, sc, sh, dy, dw, dbias, ws, ws_bytes, s, true, &other);
+        if (rc != DEVIS_OK) { *need = other; return rc2; }
+        if (rc2 == DEVIS_OK && other > *need) *need = other;
+        return DEVIS_OK;
+      }
+    }
     if (ci == 16 && co % 32 == 0 && co <= 128) WG(16, 32, 2, 2, 2, false);
     if (ci % 32 == 0 && co % 32 == 0 && ci <= 128 && co <= 128) WG(32, 32, 2, 2, 2, false);
   }
