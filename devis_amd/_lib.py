@@ -10,7 +10,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdevis_hip.so")
+# DEVIS_HIP_LIB: another build of the same library (A/B timing of kernel variants, tools/build_alt.sh)
+LIB_PATH = os.environ.get("DEVIS_HIP_LIB") or os.path.join(_HERE, "libdevis_hip.so")
 
 DEVIS_F32, DEVIS_BF16 = 0, 1
 LABEL_I64, LABEL_U8, LABEL_I32 = 0, 1, 2
