@@ -38,6 +38,10 @@ _WG_BATCH = max(1, int(_os.environ.get("DEVIS_WGRAD_BATCH", "2")))
 # handed to the side stream `a` schedule blocks after the one that issued it, the others `b` blocks after (_Run._tick)
 _WG_LAG = tuple(int(v) for v in _os.environ.get("DEVIS_WGRAD_LAG", "0:1").split(":"))
 _WG_BIG = 1 << 24
+# The main stream ends its backward before the side stream has worked off its queue (0.3 ms of weight gradients ran
+# alone at the end of the step).  DEVIS_WGRAD_TAIL_MAIN = k: the last k weight-gradient calls of the 3-D U-Net's
+# backward (InitConv; EnBlock1.conv1; EnBlock1.conv2) run on the main stream instead, beside the side stream's queue.
+_WG_TAIL_MAIN = int(_os.environ.get("DEVIS_WGRAD_TAIL_MAIN", "1"))
 
 
 # ------------------------------------------------------------ parameter holders
@@ -197,6 +201,10 @@ class _Run:
         three kernel launches' worth)."""
         if self.side is None:
             return fn(*args, **kw)
+        if self._wg_left is not None:             # the last calls of the backward (see backward()): on the main stream
+            self._wg_left -= 1
+            if self._wg_left < _WG_TAIL_MAIN:
+                return fn(*args, **kw)
         big = any(isinstance(a, Tensor) and a.numel() >= _WG_BIG for a in args)
         lag = (_WG_LAG[0] if big else _WG_LAG[1]) if self._lagged else 0
         due = max(self._blk + lag, self._last_due)          # never overtakes an earlier call
@@ -344,6 +352,7 @@ class _Run:
         d = self._conv_bwd(pop(), d, skip=ds2); tick()           # EnDown2
         d = self._en_bwd(pop(), d); tick(); d = self._en_bwd(pop(), d); tick()
         d = self._conv_bwd(pop(), d, skip=ds1); tick()           # EnDown1
+        self._wg_left = 3                                        # EnBlock1.conv2, .conv1, InitConv: the tail (_WG_TAIL_MAIN)
         d = self._en_bwd(pop(), d); tick()                       # EnBlock1
         d = self._conv_bwd(pop(), d, need_dx)                    # InitConv
         self._end_backward()
@@ -353,6 +362,8 @@ class _Run:
     def _begin_backward(self, device):
         self.side = _side_stream(device)
         self._keep, self._nev, self._pending, self._held, self._blk, self._last_due, self._lagged = [], 0, [], [], 0, 0, False
+        self._wg_left = None
+        self._joined = False
         if self.side is not None:
             self._main = torch.cuda.current_stream()
             self._events = _side_events(device)
@@ -365,15 +376,30 @@ class _Run:
             self._tick(final=True)
             self._flush_wg()
             _plan.call(self._main.wait_stream, self.side)
+            self._joined = True
         self._keep = []                           # freed behind the join, on the stream that allocated them
 
     def _bucket_done(self, i):
         if self.sync is not None:
-            if self.side is not None:             # the bucket's weight gradients come from the side stream
+            if self.side is not None and not self._joined:
+                # The bucket's weight gradients come from the side stream, which runs behind the main one.  The
+                # collective is therefore launched FROM the side stream (RCCL's stream waits for the stream that is
+                # current at the call): the side stream first waits for the main stream's part of the bucket (norm
+                # gradients; it is behind anyway), and the main stream waits for nobody.  (Joining the side stream
+                # into the main one here stalled backward until the side queue had drained: 4.93 -> see DESIGN 5.)
                 self._tick(final=True)
                 self._flush_wg()
-                _plan.call(self._main.wait_stream, self.side)
-            _plan.call(self.sync.bucket_ready, i)
+                ev = self._events[self._nev % len(self._events)]
+                self._nev += 1
+                _plan.call(ev.record, self._main)
+                _plan.call(self.side.wait_event, ev)
+                _plan.call(self._bucket_from_side, i)
+            else:
+                _plan.call(self.sync.bucket_ready, i)
+
+    def _bucket_from_side(self, i):
+        with torch.cuda.stream(self.side):
+            self.sync.bucket_ready(i)
 
 
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
