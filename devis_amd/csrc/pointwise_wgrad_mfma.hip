@@ -8,6 +8,7 @@
 // block goes to the workspace and k_reduce_partials (wgrad_reduce.h) adds the partials in a fixed order
 // (deterministic) and writes the PyTorch fp32 layouts plus dbias.
 #include "common.h"
+#include <stdlib.h>
 #include "mfma_common.h"
 #include "wgrad_reduce.h"
 
@@ -110,7 +111,10 @@ k_pw_wgrad(PwWgArgs a) {
   };
   fetch(0);
   for (int it = 0; it < a.iters; ++it) {
-    __syncthreads();
+    // The images are private to the wave and a wave's LDS instructions execute in order: no workgroup barrier between
+    // the reads of step it-1, the stores of step it and the reads of step it (it cost two s_barrier per MFMA in the
+    // 16 x 16-channel layers and kept the four waves in lockstep); wave_barrier only pins the compiler's order.
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < MTO; ++k) {
       const int i = lane + 64 * k;
@@ -133,7 +137,7 @@ k_pw_wgrad(PwWgArgs a) {
       }
       *reinterpret_cast<uint4*>(nimg + ((pc >> 1) * 32 + v) * 32 + (pc & 1) * 16) = val;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     if (it + 1 < a.iters) fetch(it + 1);
     const int vq = 4 * g + q;       // this lane addresses voxel rows vq and 16+vq of the 32-voxel step
     bf16x8 af[MTO];
@@ -235,7 +239,10 @@ static PwWgPlan pw_plan(int64_t NV, int T, int M, int N, int Cb, int nz = 1) {
   // flight on the big layers (their partials are tiny), but at most ~16 MB of partials in total
   int64_t gx = cdiv(segs, 4);
   int64_t cap = 1024 / (T * nz);
-  const int64_t by_bytes = ((int64_t)16 << 20) / ((int64_t)T * M * N * (int64_t)sizeof(float));
+  // (a partial of 64 KB or more - the 64-channel ConvT of DeUpCat4 - is worth more than the parallelism it buys: its
+  // blocks spend their time adding the four waves' tiles and writing the partial; 64 -> 16 partials: 34.6 -> 21.1 us)
+  const int64_t pbytes = (int64_t)T * M * N * (int64_t)sizeof(float);
+  const int64_t by_bytes = ((int64_t)(pbytes >= (64 << 10) ? 2 : 16) << 20) / pbytes;
   if (by_bytes < cap) cap = by_bytes;
   if (cap < 16) cap = 16;
   if (gx > cap) gx = cap;
