@@ -76,6 +76,7 @@ SIGNATURES = {
     "devis_conv_stats_chunks": (_I64, [_CD, _I, _I, _I, _I]),
     "devis_conv_fwd_stats": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _CS, _P]),
     "devis_conv_dgrad_stats": (_I, [_CD, _P, _P, _P, _P, _P, _P, _CS, _P]),
+    "devis_conv_dgrad_normbwd": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _CS, _P]),
     "devis_repack_conv_weight_dgrad": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
     "devis_conv_wgrad_workspace_bytes": (_SZ, [_CD]),
     "devis_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -41,6 +41,8 @@ int first2d_wgrad(const devis_conv_desc*, const void*, const void*, float*, floa
 // head1x1.hip: the 16 -> 4 endconv (and the 2-D nets' 32 -> 2 conv10)
 int head_fwd(const devis_conv_desc*, const void*, const void*, const float*, const void*, void*, hipStream_t);
 int head_dgrad(const devis_conv_desc*, const void*, const void*, const void*, void*, const StatsArgs*, int64_t*, hipStream_t);
+int conv3_c16_march_nb(const devis_conv_desc*, const void*, const void*, const float*, const float*, const float*, const float*,
+                       const float*, const void*, const void*, void*, void*, const StatsArgs*, hipStream_t);
 int conv3s2_dgrad_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
 // conv_s2_dgrad.hip: the same layers with the coarse tile and the weights staged in LDS
 int conv3s2_dgrad_lds(const devis_conv_desc*, const void*, const void*, const void*, void*, hipStream_t);
@@ -168,6 +170,21 @@ int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void*
   rc = conv2s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   return conv_dgrad_direct(d, dy, w, residual, dx1, dx2, s);
+}
+
+int devis_conv_dgrad_normbwd(const devis_conv_desc* d, const void* g, const void* xn, const float* scale, const float* shift,
+                             const float* cA, const float* cB, const float* cC, const void* w_dgrad, const void* residual,
+                             void* dx, void* dh_out, const devis_conv_stats* stats, void* stream) {
+  if (!conv_desc_ok(d) || !g || !xn || !scale || !shift || !cA || !cB || !cC || !w_dgrad || !dx) return DEVIS_ERR_BAD_ARG;
+  if (d->C2 != 0 || d->dtype != DEVIS_BF16 || d->C1 != d->Cout) return DEVIS_ERR_UNSUPPORTED;
+  StatsArgs st;
+  int rc = stats_args(stats, d->C1, d->N, &st);
+  if (rc) return rc;
+  // the dgrad is the forward kernel on the tap-flipped weights with the channel roles swapped (conv_dgrad_mfma)
+  devis_conv_desc t = *d;
+  t.C1 = d->Cout; t.Cout = d->C1;
+  t.ID = d->OD; t.IH = d->OH; t.IW = d->OW; t.OD = d->ID; t.OH = d->IH; t.OW = d->IW;
+  return conv3_c16_march_nb(&t, g, xn, scale, shift, cA, cB, cC, w_dgrad, residual, dx, dh_out, &st, (hipStream_t)stream);
 }
 
 int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, const void* w_dgrad,

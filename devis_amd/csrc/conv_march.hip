@@ -33,12 +33,20 @@ struct MarchArgs {
   int N, D, H, W;
   int nth, ntw, ndc, DL;
   StatsArgs st;       // norm statistics gathered in the epilogue (mode 0: off)
+  // NB (norm-backward prologue): the conv input is dh = cA * g * [sc * xn + sh > 0] + cB * xn + cC, formed from
+  // x (= g) and xn while the tile is staged (devis_norm_bwd_apply fused); sc / sh above are the gate's coefficients
+  const bf16* xn;
+  const float* cA;    // [N][16]
+  const float* cB;
+  const float* cC;
+  bf16* dh;           // dh is also written here, once (the layer's weight gradient reads it), or null
 };
 
 // FULL: H % TH == 0 and W % TW == 0 (no partial tiles -> unconditional stores)
-template <int TH, int TW, bool PRO, bool RES, bool CIN4, bool FULL, int STATS>
+template <int TH, int TW, bool PRO, bool RES, bool CIN4, bool FULL, int STATS, bool NB = false>
 __global__ void __launch_bounds__(256)
 k_conv3_c16_march(MarchArgs a) {
+  static_assert(!(NB && (PRO || CIN4)), "the norm-backward prologue replaces the affine one; 16 channels only");
   constexpr int HH = TH + 2, HW = TW + 2, HP = HH * HW;
   constexpr int NPT = (HP * 2 + 255) / 256;    // 16-byte pieces per thread per plane
   constexpr int PLB = NPT * 256 * 16;          // bytes per LDS plane (tail padding: no store guard)
@@ -102,11 +110,27 @@ k_conv3_c16_march(MarchArgs a) {
     goff[k] = ok[k] ? (unsigned)((ih * a.W + iw) * CINR + (CIN4 ? 0 : piece * 8)) : 0u;
   }
   float scv[8], shv[8];
-  if (PRO) {
+  if (PRO || NB) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       scv[j] = a.sc[n * 16 + piece * 8 + j];
       shv[j] = a.sh[n * 16 + piece * 8 + j];
+    }
+  }
+  float cav[8], cbv[8], ccv[8];
+  bool ctr[NPT];                                // NB: this piece lies in the tile itself (not in its halo ring)
+  if (NB) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cav[j] = a.cA[n * 16 + piece * 8 + j];
+      cbv[j] = a.cB[n * 16 + piece * 8 + j];
+      ccv[j] = a.cC[n * 16 + piece * 8 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int u = (tid + k * 256) >> 1;
+      const int hh = u / HW, hw = u - hh * HW;
+      ctr[k] = ok[k] && hh >= 1 && hh <= TH && hw >= 1 && hw <= TW;
     }
   }
 
@@ -135,6 +159,38 @@ k_conv3_c16_march(MarchArgs a) {
       *reinterpret_cast<uint4*>(smem + slot * PLB + (tid + k * 256) * 16) = v;
     }
   };
+  // NB: the second tensor of a plane, and the staging that forms dh (k_norm_bwd_apply's arithmetic, same rounding)
+  auto load_plane_n = [&](int id, uint4 (&rx)[NPT]) {
+    const int idc = min(max(id, 0), a.D - 1);
+    const bf16* xp = a.xn + ((size_t)n * a.D + idc) * plane * 16;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) rx[k] = *reinterpret_cast<const uint4*>(xp + goff[k]);
+  };
+  auto store_plane_nb = [&](int id, int slot, uint4 (&rg)[NPT], uint4 (&rx)[NPT]) {
+    const bool pin = id >= 0 && id < a.D;
+    const bool own = a.dh != nullptr && id >= d0 && id < d1;      // this block's planes: it writes their dh
+    const int idc = min(max(id, 0), a.D - 1);
+    bf16* hp = a.dh + ((size_t)n * a.D + idc) * plane * 16;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const unsigned gw[4] = {rg[k].x, rg[k].y, rg[k].z, rg[k].w}, xw[4] = {rx[k].x, rx[k].y, rx[k].z, rx[k].w};
+      unsigned ow[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x0 = bf_lo(xw[j]), x1 = bf_hi(xw[j]);
+        const float g0 = fmaf(x0, scv[2 * j], shv[2 * j]) > 0.f ? bf_lo(gw[j]) : 0.f;
+        const float g1 = fmaf(x1, scv[2 * j + 1], shv[2 * j + 1]) > 0.f ? bf_hi(gw[j]) : 0.f;
+        const float t0 = fmaf(cav[2 * j], g0, fmaf(cbv[2 * j], x0, ccv[2 * j]));
+        const float t1 = fmaf(cav[2 * j + 1], g1, fmaf(cbv[2 * j + 1], x1, ccv[2 * j + 1]));
+        ow[j] = pack_bf2(t0, t1);
+      }
+      uint4 v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+      const bool keep = pin && ok[k];
+      v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
+      *reinterpret_cast<uint4*>(smem + slot * PLB + (tid + k * 256) * 16) = v;
+      if (own && ctr[k]) *reinterpret_cast<uint4*>(hp + goff[k]) = v;
+    }
+  };
 
   // ---- fill the ring with planes d0-1, d0, d0+1
   {
@@ -142,9 +198,19 @@ k_conv3_c16_march(MarchArgs a) {
     load_plane(d0 - 1, r0);
     load_plane(d0, r1);
     load_plane(d0 + 1, r2);
-    store_plane(d0 - 1, 0, r0);
-    store_plane(d0, 1, r1);
-    store_plane(d0 + 1, 2, r2);
+    if (NB) {
+      uint4 q0[NPT], q1[NPT], q2[NPT];
+      load_plane_n(d0 - 1, q0);
+      load_plane_n(d0, q1);
+      load_plane_n(d0 + 1, q2);
+      store_plane_nb(d0 - 1, 0, r0, q0);
+      store_plane_nb(d0, 1, r1, q1);
+      store_plane_nb(d0 + 1, 2, r2, q2);
+    } else {
+      store_plane(d0 - 1, 0, r0);
+      store_plane(d0, 1, r1);
+      store_plane(d0 + 1, 2, r2);
+    }
   }
   __syncthreads();
 
@@ -174,8 +240,9 @@ k_conv3_c16_march(MarchArgs a) {
   const int np = d1 - d0;
   for (int it = 0; it < np; ++it) {
     const int od = d0 + it;
-    uint4 pre[NPT];
+    uint4 pre[NPT], pren[NPT];
     load_plane(od + 2, pre);                    // consumed by iteration it+1 (harmless on the last one)
+    if (NB) load_plane_n(od + 2, pren);
     const size_t pbase = ((size_t)n * a.D + od) * plane * 16;
     uint2 rv[NT];
     if (RES) {
@@ -247,7 +314,8 @@ k_conv3_c16_march(MarchArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    store_plane(od + 2, (it + 3) & (R - 1), pre);
+    if (NB) store_plane_nb(od + 2, (it + 3) & (R - 1), pre, pren);
+    else store_plane(od + 2, (it + 3) & (R - 1), pre);
     __syncthreads();
   }
   if (STATS) {
@@ -282,6 +350,17 @@ static int launch_march_s(const devis_conv_desc* d, bool full, dim3 grid, hipStr
   return launch_status();
 }
 
+// D chunk: enough blocks to fill 256 CUs about twice; each chunk re-reads 2 halo planes
+static int march_dl(int N, int nth, int ntw, int D) {
+  static int dl_env = -1;
+  if (dl_env < 0) { const char* e = getenv("DEVIS_MARCH_DL"); dl_env = e ? atoi(e) : 0; }
+  if (dl_env > 0) return dl_env;
+  int dl = 32;
+  const int64_t cols = (int64_t)N * nth * ntw;
+  while (dl > 8 && cols * cdiv(D, dl) < 512) dl >>= 1;
+  return dl;
+}
+
 // plan_chunks != null: only report the statistics chunks per sample this launch would leave
 template <int TH, int TW>
 static int launch_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
@@ -289,18 +368,11 @@ static int launch_march(const devis_conv_desc* d, const void* x, const void* w, 
                         hipStream_t s) {
   MarchArgs a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.sc = sc; a.sh = sh; a.res = (const bf16*)res; a.y = (bf16*)y;
+  a.xn = nullptr; a.cA = a.cB = a.cC = nullptr; a.dh = nullptr;
   a.N = (int)d->N; a.D = (int)d->OD; a.H = (int)d->OH; a.W = (int)d->OW;
   a.nth = (int)cdiv(a.H, TH); a.ntw = (int)cdiv(a.W, TW);
-  // D chunk: enough blocks to fill 256 CUs about twice; each chunk re-reads 2 halo planes
-  static int dl_env = -1;
-  if (dl_env < 0) { const char* e = getenv("DEVIS_MARCH_DL"); dl_env = e ? atoi(e) : 0; }
-  int dl = dl_env > 0 ? dl_env : 32;
-  if (dl_env <= 0) {
-    const int64_t cols = (int64_t)a.N * a.nth * a.ntw;
-    while (dl > 8 && cols * cdiv(a.D, dl) < 512) dl >>= 1;
-  }
-  a.DL = dl;
-  a.ndc = (int)cdiv(a.D, dl);
+  a.DL = march_dl(a.N, a.nth, a.ntw, a.D);
+  a.ndc = (int)cdiv(a.D, a.DL);
   const int64_t tiles = (int64_t)a.N * a.ndc * a.nth * a.ntw;
   if (tiles > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
   if (plan_chunks) {
@@ -318,6 +390,42 @@ static int launch_march(const devis_conv_desc* d, const void* x, const void* w, 
     return launch_march_s<TH, TW, 2>(d, full, grid, s, a);
   }
   return launch_march_s<TH, TW, 0>(d, full, grid, s, a);
+}
+
+// The same conv with the norm-backward prologue (the layer's input dh is formed from g and xn; see MarchArgs): the two
+// variants the 3-D backward uses - statistics mode 2 without a residual, a residual without statistics (or neither).
+int conv3_c16_march_nb(const devis_conv_desc* d, const void* g, const void* xn, const float* sc, const float* sh,
+                       const float* cA, const float* cB, const float* cC, const void* w, const void* res, void* y, void* dh,
+                       const StatsArgs* st, hipStream_t s) {
+  if (d->dtype != DEVIS_BF16 || d->Cout != 16 || d->C1 != 16 || d->C2 != 0 || d->SD != 1) return DEVIS_ERR_UNSUPPORTED;
+  if (d->OD != d->ID || d->OH != d->IH || d->OW != d->IW || d->OW <= 16) return DEVIS_ERR_UNSUPPORTED;
+  if (d->IH * d->IW * 16 >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
+  const int mode = st ? st->mode : 0;
+  if (mode == 1 || (mode == 2 && res)) return DEVIS_ERR_UNSUPPORTED;
+  constexpr int TH = 8, TW = 32;
+  MarchArgs a;
+  a.x = (const bf16*)g; a.w = (const bf16*)w; a.bias = nullptr; a.sc = sc; a.sh = sh; a.res = (const bf16*)res; a.y = (bf16*)y;
+  a.xn = (const bf16*)xn; a.cA = cA; a.cB = cB; a.cC = cC; a.dh = (bf16*)dh;
+  a.N = (int)d->N; a.D = (int)d->OD; a.H = (int)d->OH; a.W = (int)d->OW;
+  a.nth = (int)cdiv(a.H, TH); a.ntw = (int)cdiv(a.W, TW);
+  a.DL = march_dl(a.N, a.nth, a.ntw, a.D);     // the chunking of launch_march: devis_conv_stats_chunks counts on it
+  a.ndc = (int)cdiv(a.D, a.DL);
+  const int64_t tiles = (int64_t)a.N * a.ndc * a.nth * a.ntw;
+  if (tiles > 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
+  a.st = StatsArgs{};
+  if (mode == 2) {
+    a.st = *st;
+    if (a.st.chunks != a.ndc * a.nth * a.ntw || a.st.C != 16) return DEVIS_ERR_BAD_ARG;
+  }
+  const dim3 grid((unsigned)tiles);
+  const bool full = a.H % TH == 0 && a.W % TW == 0;
+  constexpr int LDS = 4 * (((TH + 2) * (TW + 2) * 2 + 255) / 256) * 256 * 16;
+#define NBL(RES_, FULL_, ST_) hipLaunchKernelGGL((k_conv3_c16_march<TH, TW, false, RES_, false, FULL_, ST_, true>), grid, dim3(256), LDS, s, a)
+  if (mode == 2) { if (full) NBL(false, true, 2); else NBL(false, false, 2); }
+  else if (res) { if (full) NBL(true, true, 0); else NBL(true, false, 0); }
+  else { if (full) NBL(false, true, 0); else NBL(false, false, 0); }
+#undef NBL
+  return launch_status();
 }
 
 // stride-1 3x3x3, Cout = 16, Cin = 16 (or 4: the first layer), bf16; anything else is unsupported

@@ -322,6 +322,41 @@ def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, r
     return (dx1, dx2, None) if norm is not None else (dx1, dx2)
 
 
+def conv_dgrad_normbwd(g: Tensor, xn: Tensor, scale: Tensor, shift: Tensor, coef, wp: Tensor, wd: Tensor, geom: ConvGeom,
+                       residual: Optional[Tensor] = None, norm=None, want_dh: bool = True):
+    """norm_bwd_apply fused into the dgrad that consumes it (devis_conv_dgrad_normbwd): the gradient entering this
+    conv's dgrad is dh = cA*g*[scale*xn+shift>0] + cB*xn + cC with coef = (cA, cB, cC) of norm_bwd_coeffs.
+    -> (dx, dh | None, partials | None) - the bits norm_bwd_apply + conv_dgrad give - or None when the kernel does not
+    take the layer (the caller runs the two calls)."""
+    if (g.dtype != torch.bfloat16 or g.dim() != 5 or g.shape[-1] != 16 or wp.shape[0] != 16 or wp.shape[2] != 16 or wd is None
+            or geom.k != (3, 3, 3) or geom.s != (1, 1, 1) or geom.p != (1, 1, 1) or g.shape[3] <= 16 or xn.shape != g.shape
+            or xn.dtype != g.dtype or (residual is not None and norm is not None)):
+        return None
+    _need_cuda(g, xn, scale, shift, coef[0], coef[1], coef[2], wp, wd, residual)
+    n = g.shape[0]
+    d = geom.desc(n, tuple(g.shape[1:-1]), 16, 0, 16, g.dtype)
+    lib = _lib.load()
+    st, part = None, None
+    if norm is not None:
+        xref, sc, sh = norm
+        _need_cuda(xref, sc, sh)
+        if xref.shape != g.shape or xref.dtype != g.dtype:
+            raise _lib.DevisError("dgrad statistics: the normalised tensor must have the input's shape and dtype")
+        st, part = _stats_request(lib, d, 1, 2, False, False, n, 16, g.device, xref, sc, sh)
+        if st is None:
+            return None
+    if residual is not None and residual.shape != g.shape:
+        raise _lib.DevisError("dgrad residual needs the input's shape")
+    dx = torch.empty_like(g)
+    dh = torch.empty_like(g) if want_dh else None
+    rc = lib.devis_conv_dgrad_normbwd(C.byref(d), _p(g), _p(xn), _p(scale), _p(shift), _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                      _p(wd), _p(residual), _p(dx), _p(dh), C.byref(st) if st is not None else None, _stream())
+    if rc == -2:                                   # unsupported shape: the caller runs the two calls
+        return None
+    check(rc, "conv_dgrad_normbwd")
+    return dx, dh, part
+
+
 def conv_wgrad(x1: Tensor, x2: Optional[Tensor], dy: Tensor, geom: ConvGeom, wshape,
                scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, want_bias: bool = True, out=None,
                slot: str = "ws"):
@@ -591,10 +626,16 @@ def norm_relu_bwd(dy: Tensor, x: Tensor, scale: Optional[Tensor], shift: Optiona
     if partials is None:
         partials = _moment_partials(x, dy, scale, shift)
     coef, dgamma, dbeta = norm_bwd_coeffs(partials, n, v, c, gamma, mean, rstd, groups, bn, out)
+    return norm_bwd_apply(dy, x, scale, shift, coef, extra), dgamma, dbeta
+
+
+def norm_bwd_apply(dy: Tensor, x: Tensor, scale: Tensor, shift: Tensor, coef, extra: Optional[Tensor] = None) -> Tensor:
+    """dx = cA * dy * [scale*x+shift > 0] + cB * x + cC (+ extra), coef = (cA, cB, cC) of norm_bwd_coeffs."""
+    n, v, c = _nvc(x)
     dx = torch.empty_like(x)
     check(_lib.load().devis_norm_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(coef[0]), _p(coef[1]), _p(coef[2]),
                                            _p(extra), _p(dx), n, v, c, dt_code(x.dtype), _stream()), "norm_bwd_apply")
-    return dx, dgamma, dbeta
+    return dx
 
 
 # ---------------------------------------------------------- attention gate

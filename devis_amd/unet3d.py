@@ -38,6 +38,9 @@ _WG_BATCH = max(1, int(_os.environ.get("DEVIS_WGRAD_BATCH", "2")))
 # handed to the side stream `a` schedule blocks after the one that issued it, the others `b` blocks after (_Run._tick)
 _WG_LAG = tuple(int(v) for v in _os.environ.get("DEVIS_WGRAD_LAG", "0:1").split(":"))
 _WG_BIG = 1 << 24
+# DEVIS_NO_NBWD_FUSE=1: the norm-backward elementwise pass and the dgrad that consumes it as two kernels everywhere
+# (the 16-channel layers fuse them: ops.conv_dgrad_normbwd)
+_NBWD_FUSE = _os.environ.get("DEVIS_NO_NBWD_FUSE", "0") != "1"
 # The main stream ends its backward before the side stream has worked off its queue (0.3 ms of weight gradients ran
 # alone at the end of the step).  DEVIS_WGRAD_TAIL_MAIN = k: the last k weight-gradient calls of the 3-D U-Net's
 # backward (InitConv; EnBlock1.conv1; EnBlock1.conv2) run on the main stream instead, beside the side stream's queue.
@@ -260,18 +263,36 @@ class _Run:
             return dx, pt
         return ops.conv_dgrad(dy, wp, geom, x.shape, residual=skip, wd=self._wd(name))[0] if need_dx else None
 
+    def _norm_bwd_dgrad(self, gr, xn, st, gamma, groups, bn, out, partials, cname, wfwd, residual=None, norm=None):
+        """Backward of relu(norm(xn)) followed by the dgrad of the conv `cname` that produced xn:
+        -> (dx of that conv, dh = the gradient w.r.t. xn (its weight gradient needs it), epilogue moments | None, dgamma,
+        dbeta).  At 16 channels the elementwise pass is fused into the dgrad (ops.conv_dgrad_normbwd; same bits)."""
+        n, v, c = ops._nvc(xn)
+        if partials is None:
+            partials = ops._moment_partials(xn, gr, st[0], st[1])
+        coef, dgam, dbet = ops.norm_bwd_coeffs(partials, n, v, c, gamma, st[2], st[3], groups, bn, out)
+        fused = None
+        if _NBWD_FUSE:
+            fused = ops.conv_dgrad_normbwd(gr, xn, st[0], st[1], coef, wfwd, self._wd(cname), G3, residual=residual, norm=norm)
+        if fused is not None:
+            dx, dh, pt = fused
+        else:
+            dh = ops.norm_bwd_apply(gr, xn, st[0], st[1], coef)
+            r = ops.conv_dgrad(dh, wfwd, G3, xn.shape, residual=residual, wd=self._wd(cname), norm=norm)
+            dx, pt = r[0], (r[2] if norm is not None else None)
+        return dx, dh, pt, dgam, dbet
+
     def _en_bwd(self, e, dout):
         _, name, x, h, st1, st2, w1, w2 = e
         g, P = self.grads, self.P
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = self._wg(
             ops.conv_wgrad, h, None, dout, G3, P[name + ".conv2.weight"].shape, st2[0], st2[1], out=self._o(name + ".conv2"))
         da, _, pt = ops.conv_dgrad(dout, w2, G3, h.shape, wd=self._wd(name + ".conv2"), norm=(h, st2[0], st2[1]))
-        dh, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
-            da, h, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 8, False, out=self._o(name + ".bn2"),
-            partials=pt)
+        da, dh, pt, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = self._norm_bwd_dgrad(
+            da, h, st2, P[name + ".bn2.weight"], 8, False, self._o(name + ".bn2"), pt, name + ".conv1", w1,
+            norm=(x, st1[0], st1[1]))
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = self._wg(
             ops.conv_wgrad, x, None, dh, G3, P[name + ".conv1.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv1"))
-        da, _, pt = ops.conv_dgrad(dh, w1, G3, x.shape, wd=self._wd(name + ".conv1"), norm=(x, st1[0], st1[1]))
         dx, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
             da, x, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 8, False, extra=dout,
             out=self._o(name + ".bn1"), partials=pt)
@@ -281,18 +302,16 @@ class _Run:
         _, name, x, h1, h2, st1, st2, w1, w2 = e
         g, P = self.grads, self.P
         bnm = 1 if self.training else 2       # eval mode: BatchNorm used its running statistics (constants of x)
-        dh2, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = ops.norm_relu_bwd(
-            dout, h2, st2[0], st2[1], P[name + ".bn2.weight"], st2[2], st2[3], 0, bnm, out=self._o(name + ".bn2"),
-            partials=partials)
+        da, dh2, pt, g[name + ".bn2.weight"], g[name + ".bn2.bias"] = self._norm_bwd_dgrad(
+            dout, h2, st2, P[name + ".bn2.weight"], 0, bnm, self._o(name + ".bn2"), partials, name + ".conv2", w2,
+            norm=(h1, st1[0], st1[1]))
         g[name + ".conv2.weight"], g[name + ".conv2.bias"] = self._wg(
             ops.conv_wgrad, h1, None, dh2, G3, P[name + ".conv2.weight"].shape, st1[0], st1[1], out=self._o(name + ".conv2"))
-        da, _, pt = ops.conv_dgrad(dh2, w2, G3, h1.shape, wd=self._wd(name + ".conv2"), norm=(h1, st1[0], st1[1]))
-        dh1, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = ops.norm_relu_bwd(
-            da, h1, st1[0], st1[1], P[name + ".bn1.weight"], st1[2], st1[3], 0, bnm, out=self._o(name + ".bn1"),
-            partials=pt)
+        dx, dh1, _, g[name + ".bn1.weight"], g[name + ".bn1.bias"] = self._norm_bwd_dgrad(
+            da, h1, st1, P[name + ".bn1.weight"], 0, bnm, self._o(name + ".bn1"), pt, name + ".conv1", w1, residual=dout)
         g[name + ".conv1.weight"], g[name + ".conv1.bias"] = self._wg(
             ops.conv_wgrad, x, None, dh1, G3, P[name + ".conv1.weight"].shape, out=self._o(name + ".conv1"))
-        return ops.conv_dgrad(dh1, w1, G3, x.shape, residual=dout, wd=self._wd(name + ".conv1"))[0]
+        return dx
 
     def _up_bwd(self, e, dy):
         g, P = self.grads, self.P

@@ -135,6 +135,16 @@ int devis_conv_fwd_stats(const devis_conv_desc* d, const void* x1, const void* x
                          void* y, const devis_conv_stats* stats, void* stream);
 int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void* w_packed, const void* w_dgrad,
                            const void* residual, void* dx1, void* dx2, const devis_conv_stats* stats, void* stream);
+/* devis_norm_bwd_apply (below) fused into the dgrad that consumes its result: the gradient that enters this conv's
+ * dgrad is dh = cA * g * [scale * xn + shift > 0] + cB * xn + cC - autograd's backward of the norm + ReLU in front of the
+ * conv (UNet3DZoo.py:12-15,44-56,149-165) - formed from g and xn while the tile is staged, with devis_norm_bwd_apply's
+ * arithmetic and rounding (same bits as the two calls).  dh_out (may be NULL) receives dh once: the layer's weight
+ * gradient reads it.  g, xn, dh_out: the conv OUTPUT's shape; scale .. cC: [N][Cout] (devis_norm_bwd_finalize*);
+ * residual / dx / stats as devis_conv_dgrad_stats (a residual and statistics exclude each other).  bf16, 3x3x3 stride 1,
+ * 16 -> 16 channels, W > 16 only: DEVIS_ERR_UNSUPPORTED otherwise (run the two calls). */
+int devis_conv_dgrad_normbwd(const devis_conv_desc* d, const void* g, const void* xn, const float* scale,
+                             const float* shift, const float* cA, const float* cB, const float* cC, const void* w_dgrad,
+                             const void* residual, void* dx, void* dh_out, const devis_conv_stats* stats, void* stream);
 /* dw [Cout][C1+C2][T] fp32 (PyTorch layout) and dbias [Cout] fp32 (may be NULL).
  * The conv input is recomputed from x1/x2 with the same prologue. */
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d);

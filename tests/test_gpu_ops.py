@@ -455,3 +455,47 @@ def test_conv_epilogue_backward_moments(case):
     close(a[0].float().cpu(), r[0].float().cpu(), torch.bfloat16, "dx via epilogue moments vs separate pass")
     close32(a[1], r[1], torch.bfloat16, "dgamma")
     close32(a[2], r[2], torch.bfloat16, "dbeta")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 12, 20, 36), (2, 40, 10, 48)])
+@pytest.mark.parametrize("variant", ["stats", "residual", "plain"])
+def test_conv_dgrad_with_norm_backward_prologue(shape, variant):
+    """devis_conv_dgrad_normbwd = devis_norm_bwd_apply + devis_conv_dgrad(_stats) in one kernel: dx, the dh it writes
+    out for the weight gradient and the epilogue moments carry the bits of the two calls (several D chunks, ragged
+    tiles, planes at the volume's border)."""
+    from devis_amd import ops
+    n, d, h, w = shape
+    g = torch.Generator().manual_seed(d * 100 + w)
+    bf = lambda t: t.bfloat16().cuda()
+    gg, xn = bf(torch.randn((n, d, h, w, 16), generator=g)), bf(torch.randn((n, d, h, w, 16), generator=g))
+    sc = (torch.rand((n, 16), generator=g) + 0.5).cuda()
+    sh = (torch.randn((n, 16), generator=g) * 0.3).cuda()
+    coef = (torch.randn((3, n, 16), generator=g) * 0.5).cuda()
+    wt = (torch.randn((16, 16, 3, 3, 3), generator=g) * 0.1).cuda()
+    G3 = ops.ConvGeom((3, 3, 3), (1, 1, 1), (1, 1, 1))
+    wp = ops.pack_conv_weight(wt, torch.bfloat16)
+    wd = torch.empty((wp.shape[2], wp.shape[1], wp.shape[0]), dtype=wp.dtype, device=wp.device)
+    from devis_amd import _lib
+    _lib.check(_lib.load().devis_repack_conv_weight_dgrad(wp.data_ptr(), wd.data_ptr(), 16, 16, 27, _lib.DEVIS_BF16,
+                                                          torch.cuda.current_stream().cuda_stream), "repack")
+    res = bf(torch.randn((n, d, h, w, 16), generator=g)) if variant == "residual" else None
+    xref = bf(torch.randn((n, d, h, w, 16), generator=g))
+    sc2 = (torch.rand((n, 16), generator=g) + 0.5).cuda()
+    sh2 = (torch.randn((n, 16), generator=g) * 0.3).cuda()
+    norm = (xref, sc2, sh2) if variant == "stats" else None
+    # the two calls
+    dh_ref = torch.empty_like(gg)
+    nv = d * h * w
+    _lib.check(_lib.load().devis_norm_bwd_apply(gg.data_ptr(), xn.data_ptr(), sc.data_ptr(), sh.data_ptr(), coef[0].data_ptr(),
+                                                coef[1].data_ptr(), coef[2].data_ptr(), None, dh_ref.data_ptr(), n, nv, 16,
+                                                _lib.DEVIS_BF16, torch.cuda.current_stream().cuda_stream), "apply")
+    out = ops.conv_dgrad(dh_ref, wp, G3, gg.shape, residual=res, wd=wd, norm=norm)
+    dx_ref, part_ref = out[0], (out[2] if norm is not None else None)
+    fused = ops.conv_dgrad_normbwd(gg, xn, sc, sh, coef, wp, wd, G3, residual=res, norm=norm)
+    assert fused is not None
+    dx, dh, part = fused
+    torch.cuda.synchronize()
+    assert torch.equal(dh, dh_ref)
+    assert torch.equal(dx, dx_ref)
+    if norm is not None:
+        assert part[1] == part_ref[1] and torch.equal(part[0], part_ref[0])
