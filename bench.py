@@ -246,8 +246,8 @@ def main():
         # HBM bytes per launch of THIS kernel from the tracked counter passes (profiles/r02_pmc_step.json, made by
         # tools/pmc_step.sh on the shipped build: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), looked up by
         # kernel name and scaled with the voxel count; null when the file or the kernel is missing.
-        traffic, pmc_mfma_util = pmc_lookup(("k_conv3_c16_march<8, 32, true, false, false, true, 0>",), a.batch * S ** 3, dtype)
-        out["roofline"] = {"kernel": "k_conv3_c16_march<8, 32, true, false, false, true, 0> (" + name + ": 16->16 3x3x3, GroupNorm+ReLU prologue)", "bound": "hbm",
+        traffic, pmc_mfma_util = pmc_lookup(("k_conv3_c16_march<8, 32, true, false, false, true, 0, false>",), a.batch * S ** 3, dtype)
+        out["roofline"] = {"kernel": "k_conv3_c16_march<8, 32, true, false, false, true, 0, false> (" + name + ": 16->16 3x3x3, GroupNorm+ReLU prologue)", "bound": "hbm",
                            "achieved": alg_bytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": alg_bytes / t / 1e9 / PEAK_HBM_GBS, "traffic": traffic,
                            "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
