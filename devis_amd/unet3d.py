@@ -36,7 +36,7 @@ _UPCAT_BWD_FUSE = _os.environ.get("DEVIS_NO_UPCAT_BWD_FUSE", "0") != "1"
 _WG_BATCH = max(1, int(_os.environ.get("DEVIS_WGRAD_BATCH", "2")))
 # DEVIS_WGRAD_LAG = "a:b": a weight-gradient call on tensors of >= _WG_BIG elements (the full-resolution layers) is
 # handed to the side stream `a` schedule blocks after the one that issued it, the others `b` blocks after (_Run._tick)
-_WG_LAG = tuple(int(v) for v in _os.environ.get("DEVIS_WGRAD_LAG", "0:1").split(":"))
+_WG_LAG = tuple(int(v) for v in _os.environ.get("DEVIS_WGRAD_LAG", "1:2").split(":"))
 _WG_BIG = 1 << 24
 # DEVIS_NO_NBWD_FUSE=1: the norm-backward elementwise pass and the dgrad that consumes it as two kernels everywhere
 # (the 16-channel layers fuse them: ops.conv_dgrad_normbwd)
@@ -208,6 +208,7 @@ class _Run:
             self._wg_left -= 1
             if self._wg_left < _WG_TAIL_MAIN:
                 return fn(*args, **kw)
+        self._wg_seq += 1
         big = any(isinstance(a, Tensor) and a.numel() >= _WG_BIG for a in args)
         lag = (_WG_LAG[0] if big else _WG_LAG[1]) if self._lagged else 0
         due = max(self._blk + lag, self._last_due)          # never overtakes an earlier call
@@ -245,6 +246,9 @@ class _Run:
             for fn, args, kw in pend:
                 fn(*args, slot="ws_side", **kw)
                 self._keep.append(args)
+        self._wg_issued += len(pend)
+        if self.sync is not None:
+            self._launch_ready_buckets()
 
     def _next_norm(self):
         """(h2, scale, shift) of the DeBlock whose backward comes next on the tape: its bn2+ReLU backward needs
@@ -383,6 +387,7 @@ class _Run:
         self._keep, self._nev, self._pending, self._held, self._blk, self._last_due, self._lagged = [], 0, [], [], 0, 0, False
         self._wg_left = None
         self._joined = False
+        self._wg_seq, self._wg_issued, self._bucket_wait = 0, 0, []
         if self.side is not None:
             self._main = torch.cuda.current_stream()
             self._events = _side_events(device)
@@ -394,6 +399,8 @@ class _Run:
         if self.side is not None:
             self._tick(final=True)
             self._flush_wg()
+            if self.sync is not None:
+                self._launch_ready_buckets()
             _plan.call(self._main.wait_stream, self.side)
             self._joined = True
         self._keep = []                           # freed behind the join, on the stream that allocated them
@@ -401,20 +408,26 @@ class _Run:
     def _bucket_done(self, i):
         if self.sync is not None:
             if self.side is not None and not self._joined:
-                # The bucket's weight gradients come from the side stream, which runs behind the main one.  The
-                # collective is therefore launched FROM the side stream (RCCL's stream waits for the stream that is
-                # current at the call): the side stream first waits for the main stream's part of the bucket (norm
-                # gradients; it is behind anyway), and the main stream waits for nobody.  (Joining the side stream
-                # into the main one here stalled backward until the side queue had drained: 4.93 -> see DESIGN 5.)
-                self._tick(final=True)
-                self._flush_wg()
-                ev = self._events[self._nev % len(self._events)]
-                self._nev += 1
-                _plan.call(ev.record, self._main)
-                _plan.call(self.side.wait_event, ev)
-                _plan.call(self._bucket_from_side, i)
+                # The bucket's weight gradients come from the side stream, which runs behind the main one, and some of
+                # them are still held back by the hand-over lag (_wg).  The collective is therefore launched FROM the
+                # side stream (RCCL's stream waits for the stream that is current at the call) once the last of the
+                # bucket's weight-gradient calls has been handed over; the side stream first waits for the main
+                # stream's part of the bucket (norm gradients), and the main stream waits for nobody.  (Joining the
+                # side stream into the main one here stalled backward until the side queue had drained, and flushing
+                # the held calls here gave up what the lag buys: DESIGN 5.)
+                self._bucket_wait.append((i, self._wg_seq))
+                self._launch_ready_buckets()
             else:
                 _plan.call(self.sync.bucket_ready, i)
+
+    def _launch_ready_buckets(self):
+        while self._bucket_wait and self._bucket_wait[0][1] <= self._wg_issued:
+            i, _ = self._bucket_wait.pop(0)
+            ev = self._events[self._nev % len(self._events)]
+            self._nev += 1
+            _plan.call(ev.record, self._main)
+            _plan.call(self.side.wait_event, ev)
+            _plan.call(self._bucket_from_side, i)
 
     def _bucket_from_side(self, i):
         with torch.cuda.stream(self.side):
