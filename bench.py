@@ -202,8 +202,11 @@ def main():
 
     from devis_amd.train import freeze_gc
     freeze_gc()                                # as devis_amd.train.train() does before its loop
+    trace = [] if os.environ.get("DEVIS_BENCH_TRACE_LOSS") == "1" else None   # debugging aid: every step's loss
     for _ in range(a.warmup):
         loss = step()
+        if trace is not None:
+            trace.append(loss.detach().clone())
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -220,6 +223,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = float(loss.item())
+    if final_loss != final_loss or abs(final_loss) == float("inf"):
+        raise SystemExit("bench.py: the training loss is not finite after %d steps (%r): the timing is void"
+                         % (a.warmup + a.steps, final_loss))
+    if trace is not None:
+        print("warmup losses:", " ".join("%.6f" % float(v) for v in trace), file=sys.stderr)
     vox = world * a.batch * S ** 3 * a.steps
     out = {
         "metric": "train voxels/sec (fwd+bwd+evid loss), BraTS 4x128^3 K=4",

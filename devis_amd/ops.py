@@ -91,16 +91,50 @@ _ws = {}
 _ws_retired = []
 
 
+def _persistent(make, filled_on=None):
+    """Run an allocation whose result OUTLIVES the step (workspaces, constant tables) so that it does not land in a
+    launch plan's memory pool.  While a step is being recorded the thread's allocations come from the plan's private
+    pool (launch_plan.StepPlan.recording), whose addresses the replay hands out again in the recorded order: a buffer
+    allocated there at step time t sits where some tensor of the step lived BEFORE t, and a user of the buffer that
+    runs earlier in a later step (the loss head's workspace between forward and backward, another model) would
+    overwrite that tensor.  torch routes only the recording thread's allocations to the pool (torch.cuda.use_mem_pool),
+    so the allocation is made on a helper thread; it is rare (first use, growth).  `filled_on` = the device to
+    synchronise when `make` also launches fills (they run on the helper thread's stream)."""
+    if not _lib._recorders or getattr(_lib._rec_tls, "rec", None) is None:
+        return make()
+    import threading
+    box = []
+
+    def run():
+        try:
+            out = make()
+            if filled_on is not None:
+                torch.cuda.synchronize(filled_on)
+            box.append((out, None))
+        except BaseException as e:          # re-raised on the calling thread
+            box.append((None, e))
+
+    th = threading.Thread(target=run)
+    th.start()
+    th.join()
+    out, err = box[0]
+    if err is not None:
+        raise err
+    return out
+
+
 def workspace(nbytes: int, device: torch.device, slot: str = "ws") -> Tensor:
     """Scratch that only ever grows (the library itself never allocates), one buffer per (device, slot, STREAM the
     calls launch on): kernels of different streams run concurrently and must not share it.  A buffer that is
-    outgrown is retired, not freed - a captured HIP graph may still hold its address."""
+    outgrown is retired, not freed - a recorded launch plan or a captured HIP graph may still hold its address.
+    Never allocated from a launch plan's pool (_persistent)."""
     key = (device.index, slot, _stream())
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
         if t is not None:
             _ws_retired.append(t)
-        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        size = max(nbytes, 1 << 20)
+        t = _persistent(lambda: torch.empty(size, dtype=torch.uint8, device=device))
         _ws[key] = t
     return t
 
@@ -593,8 +627,10 @@ def _open_gate(n: int, c: int, device):
     key = (n, c, device.index)
     g = _gate_cache.get(key)
     if g is None:
-        g = _gate_cache[key] = (torch.zeros((n, c), dtype=torch.float32, device=device),
-                                torch.ones((n, c), dtype=torch.float32, device=device))
+        def make():                        # constants that outlive the step: not from a launch plan's pool
+            return (torch.zeros((n, c), dtype=torch.float32, device=device),
+                    torch.ones((n, c), dtype=torch.float32, device=device))
+        g = _gate_cache[key] = _persistent(make, filled_on=device)
     return g
 
 

@@ -140,3 +140,45 @@ def test_unetdrop_is_not_planned():
     for _ in range(2):
         m(x).sum().backward()
     assert not getattr(m, "_plans", {})
+
+
+def _drop_workspaces():
+    """as in a fresh process: the first recorded step has to create (and grow) every workspace"""
+    from devis_amd import ops
+    ops._ws_retired.extend(ops._ws.values())
+    ops._ws.clear()
+    ops._gate_cache.clear()
+
+
+@pytest.mark.parametrize("model_name", ["U", "AU"])
+def test_buffers_that_outlive_the_step_are_not_in_the_plans_pool(model_name):
+    """Workspaces and constant tables created WHILE a step is recorded must not come from the plan's pool: the replay
+    hands that address to a tensor of the step again, and a later user of the buffer (the loss head between forward
+    and backward) overwrote an activation - NaN gradients from the first replayed step of a fresh process on."""
+    from devis_amd import ops
+    _drop_workspaces()
+    l1, sd1, p1 = _train(4, True, model_name=model_name)
+    plan = next(iter(p1.values()))
+    segs = [(s["address"], s["address"] + s["total_size"]) for s in plan.pool.snapshot()]
+    assert segs
+    held = list(ops._ws.values()) + list(ops._ws_retired) + [t for g in ops._gate_cache.values() for t in g]
+    assert ops._ws
+    for t in held:
+        assert not any(a <= t.data_ptr() < b for a, b in segs), "a persistent buffer lies in the launch plan's pool"
+    l0, sd0, _ = _train(4, False, model_name=model_name)
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+
+
+def test_first_replay_of_a_fresh_process_equals_eager_at_the_bench_shape():
+    """tools/lag_diff.py in a process of its own (2 x 4 x 128^3, the default weight-gradient lag): record, replay,
+    compare every gradient with an eager run.  This is the case bench.py and train() start with."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from devis_amd import unet3d
+    lag = "%d:%d" % unet3d._WG_LAG
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "lag_diff.py"), lag], capture_output=True, text=True,
+                         timeout=110, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "tensors differing: 0" in out.stdout, out.stdout[-2000:]
