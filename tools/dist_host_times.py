@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Host time of each part of a data-parallel training step (one-rank RCCL group): where does the host wait?
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29540 python tools/dist_host_times.py"""
-import os, sys, time, torch
+import faulthandler, os, sys, time, torch
+faulthandler.dump_traceback_later(40, exit=True)      # a hang names its line and ends
 import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from devis_amd import TMSU
@@ -29,6 +30,8 @@ for it in range(40):
     opt.zero_grad(set_to_none=True); loss.backward(); t.append(time.perf_counter())
     red.all_reduce(); t.append(time.perf_counter())
     opt.step(); t.append(time.perf_counter())
+    if os.environ.get("SYNC_EVERY") and it % int(os.environ["SYNC_EVERY"]) == 0:
+        torch.cuda.synchronize()
     if it >= 10:
         for k in range(4): acc[k].append((t[k + 1] - t[k]) * 1e3)
 torch.cuda.synchronize()
