@@ -44,7 +44,7 @@ _NBWD_FUSE = _os.environ.get("DEVIS_NO_NBWD_FUSE", "0") != "1"
 # The main stream ends its backward before the side stream has worked off its queue (0.3 ms of weight gradients ran
 # alone at the end of the step).  DEVIS_WGRAD_TAIL_MAIN = k: the last k weight-gradient calls of the 3-D U-Net's
 # backward (InitConv; EnBlock1.conv1; EnBlock1.conv2) run on the main stream instead, beside the side stream's queue.
-_WG_TAIL_MAIN = int(_os.environ.get("DEVIS_WGRAD_TAIL_MAIN", "1"))
+_WG_TAIL_MAIN = int(_os.environ.get("DEVIS_WGRAD_TAIL_MAIN", "2"))
 
 
 # ------------------------------------------------------------ parameter holders
