@@ -171,7 +171,8 @@ def main():
         _side_stream(dev)
     if multi:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        from devis_amd.parallel import nccl_options
+        dist.init_process_group("nccl", device_id=dev, pg_options=nccl_options())
     from devis_amd import TMSU
     from devis_amd.parallel import GradientAllReducer
     from devis_amd.optim import FusedAdam

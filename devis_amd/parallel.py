@@ -16,10 +16,11 @@ import torch.distributed as dist
 
 
 # The backbones mark three points of their backward at which a slice of the flat gradient buffer is final (decoder;
-# the deepest stage; the rest).  Every collective costs the step 70-90 us however small it is (one-rank rehearsal:
-# three all-reduces +0.28 ms, the same stream/event traffic without them +0.00), and the first slice has the whole
-# encoder's backward left to hide behind, so the first two slices go out as ONE all-reduce at the second mark
-# (4.89 -> 4.82 ms).  DEVIS_DP_BUCKETS=3 sends them separately.
+# the deepest stage; the rest).  The first slice has the whole encoder's backward left to hide behind, and every
+# collective has a fixed cost of its own (launch, ring latency), so the first two slices go out as ONE all-reduce at the
+# second mark.  (Measured in the one-rank rehearsal while RCCL's stream still shared the
+# main stream's queue: three all-reduces +0.28 ms, two +0.21; with nccl_options two or three make no difference there,
+# 4.606 / 4.603 ms.)  DEVIS_DP_BUCKETS=3 sends them separately.
 _MERGE_FIRST_TWO = os.environ.get("DEVIS_DP_BUCKETS", "2") == "2"
 
 
@@ -126,6 +127,20 @@ class GradientAllReducer:
                     p.grad = torch.empty_like(p)
                 p.grad.copy_(flat[off:off + n].view_as(p))
                 off += n
+
+
+def nccl_options():
+    """Options for ``dist.init_process_group("nccl", pg_options=...)`` of a data-parallel training process.
+    torch launches RCCL's kernels on a stream of its own; taken from the normal-priority pool that stream shared the
+    MAIN stream's hardware queue on MI355X (kernel trace: both on one queue id), and a hardware queue is in-order: a
+    bucket's all-reduce, which has to wait for the side stream's weight gradients, held back every backward kernel the
+    main stream had queued behind it (70-90 us of the main stream standing still per collective).  From the
+    high-priority pool it gets a hardware queue of its own (a third queue id in the trace; main and side keep theirs) and
+    waits there alone: one-rank rehearsal 4.713 -> 4.571 ms beside a plain step of 4.495.  DEVIS_NCCL_HIGH_PRIORITY=0:
+    torch's default."""
+    if os.environ.get("DEVIS_NCCL_HIGH_PRIORITY", "1") == "0":
+        return None
+    return dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:

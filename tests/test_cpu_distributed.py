@@ -111,3 +111,15 @@ def test_sharded_sliding_window_gloo(world):
     # and the evidence map is exactly what the reference's stitch gives for the same per-patch function
     ref = tailor_and_concat(torch.cat([x, x], 1), lambda t: t * 2 + 1)[:, :2]
     assert torch.equal(single["evidence"], ref)
+
+
+def test_flat_grad_sync_sends_the_first_two_slices_together():
+    """devis_amd/parallel.py: three marks in backward, two collectives (DEVIS_DP_BUCKETS, default 2)"""
+    import torch
+    from devis_amd import parallel
+    s = parallel.FlatGradSync(2)
+    flat = torch.zeros(12)
+    s.begin(flat, [(0, 4), (4, 10), (10, 12)])
+    assert s.bounds == ([(0, 0), (0, 10), (10, 12)] if parallel._MERGE_FIRST_TWO else [(0, 4), (4, 10), (10, 12)])
+    s.bucket_ready(0) if parallel._MERGE_FIRST_TWO else None     # an empty slice launches nothing (no process group here)
+    assert s.works == []

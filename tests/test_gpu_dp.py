@@ -32,7 +32,7 @@ def _free_port():
 def test_one_rank_rccl_bucketed_allreduce_is_bit_identical():
     import torch.distributed as dist
     from devis_amd import TMSU
-    from devis_amd.parallel import GradientAllReducer
+    from devis_amd.parallel import GradientAllReducer, nccl_options
     torch.manual_seed(0)
     m = TMSU(brats_args(compute_dtype=torch.bfloat16)).train()
     g = torch.Generator().manual_seed(1234)
@@ -52,7 +52,8 @@ def test_one_rank_rccl_bucketed_allreduce_is_bit_identical():
     ref, loss_ref = step(None)
     assert dist.is_available() and not dist.is_initialized()
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
-                            device_id=torch.device("cuda", torch.cuda.current_device()))
+                            device_id=torch.device("cuda", torch.cuda.current_device()),
+                            pg_options=nccl_options())       # as bench.py / INTEGRATION.md set the group up
     try:
         reducer = GradientAllReducer(m.parameters(), module=m, force=True)
         assert reducer.active and reducer.flat_sync is not None and reducer.flat_sync._avg
