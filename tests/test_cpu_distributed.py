@@ -123,3 +123,12 @@ def test_flat_grad_sync_sends_the_first_two_slices_together():
     assert s.bounds == ([(0, 0), (0, 10), (10, 12)] if parallel._MERGE_FIRST_TWO else [(0, 4), (4, 10), (10, 12)])
     s.bucket_ready(0) if parallel._MERGE_FIRST_TWO else None     # an empty slice launches nothing (no process group here)
     assert s.works == []
+
+
+def test_nccl_options_ask_for_a_high_priority_stream(monkeypatch):
+    """devis_amd/parallel.py:nccl_options - what bench.py passes to init_process_group"""
+    from devis_amd import parallel
+    monkeypatch.delenv("DEVIS_NCCL_HIGH_PRIORITY", raising=False)
+    assert parallel.nccl_options().is_high_priority_stream is True
+    monkeypatch.setenv("DEVIS_NCCL_HIGH_PRIORITY", "0")
+    assert parallel.nccl_options() is None
