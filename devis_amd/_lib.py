@@ -132,7 +132,6 @@ _lib = None
 
 # ---- launch recording (devis_amd/launch_plan.py): while a thread records, load() hands it a proxy that notes every
 # launching call (function, arguments) after making it.  Host-only queries are not noted.
-_recorders = 0                       # threads recording right now (fast path: 0)
 _rec_tls = threading.local()         # .rec: the thread's Recorder
 _NOT_LAUNCHES = ("_bytes", "_chunks", "_supported")
 
@@ -173,7 +172,7 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
-    if _recorders and getattr(_rec_tls, "rec", None) is not None:
+    if getattr(_rec_tls, "rec", None) is not None:     # thread-local only: no shared counter to lose an update of
         if _recording_lib is None:
             _recording_lib = _RecordingLib(_lib)
         return _recording_lib

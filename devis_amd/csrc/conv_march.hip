@@ -397,9 +397,14 @@ static int launch_march(const devis_conv_desc* d, const void* x, const void* w, 
 int conv3_c16_march_nb(const devis_conv_desc* d, const void* g, const void* xn, const float* sc, const float* sh,
                        const float* cA, const float* cB, const float* cC, const void* w, const void* res, void* y, void* dh,
                        const StatsArgs* st, hipStream_t s) {
-  if (d->dtype != DEVIS_BF16 || d->Cout != 16 || d->C1 != 16 || d->C2 != 0 || d->SD != 1) return DEVIS_ERR_UNSUPPORTED;
+  if (d->dtype != DEVIS_BF16 || d->Cout != 16 || d->C1 != 16 || d->C2 != 0) return DEVIS_ERR_UNSUPPORTED;
+  // this entry is reached straight from the C ABI (devis_conv_dgrad_normbwd), not through conv_fwd_mfma's checks: the
+  // kernel walks 27 taps of a pad-1 stride-1 layer and indexes with 32-bit offsets, so anything else is refused here
+  if (d->KD != 3 || d->KH != 3 || d->KW != 3 || d->PD != 1 || d->PH != 1 || d->PW != 1 || d->SD != 1 || d->SH != 1 || d->SW != 1)
+    return DEVIS_ERR_UNSUPPORTED;
   if (d->OD != d->ID || d->OH != d->IH || d->OW != d->IW || d->OW <= 16) return DEVIS_ERR_UNSUPPORTED;
   if (d->IH * d->IW * 16 >= (int64_t)1 << 31) return DEVIS_ERR_UNSUPPORTED;
+  if (d->N * d->ID * d->IH * d->IW * 16 >= (int64_t)1 << 32 || d->N * d->ID * d->IH * d->IW >= 0x7fffffff) return DEVIS_ERR_UNSUPPORTED;
   const int mode = st ? st->mode : 0;
   if (mode == 1 || (mode == 2 && res)) return DEVIS_ERR_UNSUPPORTED;
   constexpr int TH = 8, TW = 32;

@@ -634,12 +634,12 @@ __device__ __forceinline__ float dce4_voxel(const float* z, int y, float lambda,
 
 template <typename T, int LDT, bool EVOUT, bool PVOUT>
 __global__ void __launch_bounds__(256)
-k_dce4_fwd(const T* __restrict__ z, const void* __restrict__ labels, int64_t V, float lambda,
+k_dce4_fwd(const T* __restrict__ z, int64_t sN, const void* __restrict__ labels, int64_t V, float lambda,
            float* __restrict__ evidence_out, float* __restrict__ per_voxel_out, double* __restrict__ partial) {
   const float lgK = 1.791759469228055f;                    // ln Gamma(4) = ln 6
   const int64_t n = blockIdx.y;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  const T* zn = z + n * V * 4;
+  const T* zn = z + n * sN;                                 // the sample stride is the caller's (>= 4 V, a multiple of 4)
   float apv = 0.f, aI[4] = {0.f, 0.f, 0.f, 0.f}, aP[4] = {0.f, 0.f, 0.f, 0.f};
   int rc[4] = {0, 0, 0, 0};                                 // wave-uniform label counts
   for (int64_t v0 = (int64_t)blockIdx.x * 256 + threadIdx.x; v0 < V; v0 += 2 * stride) {
@@ -725,7 +725,7 @@ __device__ __forceinline__ void dce4_voxel_bwd(const float* z, int y, float lamb
 
 template <typename T, int LDT, bool GEV>
 __global__ void __launch_bounds__(256)
-k_dce4_bwd(const T* __restrict__ z, const void* __restrict__ labels, int64_t N, int64_t V, float lambda,
+k_dce4_bwd(const T* __restrict__ z, int64_t sN, const void* __restrict__ labels, int64_t N, int64_t V, float lambda,
            const float* __restrict__ scal, const float* __restrict__ grad_loss, const float* __restrict__ grad_ev,
            T* __restrict__ dz) {
   const float gl = grad_loss[0];
@@ -739,8 +739,8 @@ k_dce4_bwd(const T* __restrict__ z, const void* __restrict__ labels, int64_t N, 
   }
   const int64_t n = blockIdx.y;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  const T* zn = z + n * V * 4;
-  T* dn = dz + n * V * 4;
+  const T* zn = z + n * sN;
+  T* dn = dz + n * sN;
   for (int64_t v0 = (int64_t)blockIdx.x * 256 + threadIdx.x; v0 < V; v0 += 2 * stride) {
     const int64_t v1 = v0 + stride;
     const bool two = v1 < V;
@@ -886,7 +886,7 @@ int devis_evid_crit_fwd(const devis_evid_params* p, const void* in, int64_t sN, 
   double* part = scal ? (double*)ws : nullptr;
   if (p->kind == CRIT_DCE && !p->input_kind && !evidence_in && sh.vec) {
     // the training hot path (K = 4 is implied by vec): the straight-line kernel
-#define LAUNCH_DCE4(LDT, EV, PV) hipLaunchKernelGGL((k_dce4_fwd<T, LDT, EV, PV>), grid2, dim3(256), 0, s, (const T*)in, labels, V, p->lambda, evidence_out, per_voxel_out, part)
+#define LAUNCH_DCE4(LDT, EV, PV) hipLaunchKernelGGL((k_dce4_fwd<T, LDT, EV, PV>), grid2, dim3(256), 0, s, (const T*)in, sN, labels, V, p->lambda, evidence_out, per_voxel_out, part)
 #define LAUNCH_DCE4_L(LDT) do { if (evidence_out && per_voxel_out) LAUNCH_DCE4(LDT, true, true); else if (evidence_out) LAUNCH_DCE4(LDT, true, false); else if (per_voxel_out) LAUNCH_DCE4(LDT, false, true); else LAUNCH_DCE4(LDT, false, false); } while (0)
     DEVIS_DISPATCH_DTYPE(dtype, {
       if (label_dtype == DEVIS_LABEL_I64) LAUNCH_DCE4_L(DEVIS_LABEL_I64);
@@ -918,7 +918,7 @@ int devis_evid_crit_bwd(const devis_evid_params* p, const void* in, int64_t sN, 
   if (p->kind == CRIT_DCE && !p->input_kind && !evidence_in && sh.vec && grad_loss && !grad_pv) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid2 = ev_grid2(N, V);
-#define LAUNCH_DCE4B(LDT, GEV) hipLaunchKernelGGL((k_dce4_bwd<T, LDT, GEV>), grid2, dim3(256), 0, s, (const T*)in, labels, N, V, p->lambda, scal, grad_loss, grad_ev, (T*)d_in)
+#define LAUNCH_DCE4B(LDT, GEV) hipLaunchKernelGGL((k_dce4_bwd<T, LDT, GEV>), grid2, dim3(256), 0, s, (const T*)in, sN, labels, N, V, p->lambda, scal, grad_loss, grad_ev, (T*)d_in)
 #define LAUNCH_DCE4B_L(LDT) do { if (grad_ev) LAUNCH_DCE4B(LDT, true); else LAUNCH_DCE4B(LDT, false); } while (0)
     DEVIS_DISPATCH_DTYPE(dtype, {
       if (label_dtype == DEVIS_LABEL_I64) LAUNCH_DCE4B_L(DEVIS_LABEL_I64);

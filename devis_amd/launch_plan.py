@@ -42,7 +42,7 @@ def current():
 def call(fn, *args):
     """Run a host-side action that belongs to the step (event record, stream wait, collective launch) and, when the
     thread is recording, note it as ONE replayable entry: launches made inside it are not noted a second time."""
-    rec = getattr(_lib._rec_tls, "rec", None) if _lib._recorders else None
+    rec = getattr(_lib._rec_tls, "rec", None)
     if rec is None or rec.opaque:
         return fn(*args)
     rec.opaque += 1
@@ -96,12 +96,10 @@ class StepPlan:
     def recording(self):
         rec = Recorder()
         _lib._rec_tls.rec = rec
-        _lib._recorders += 1
         try:
             with torch.cuda.use_mem_pool(self.pool, self.device):
                 yield rec
         finally:
-            _lib._recorders -= 1
             _lib._rec_tls.rec = None
 
     def ready(self) -> bool:

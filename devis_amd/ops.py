@@ -100,7 +100,7 @@ def _persistent(make, filled_on=None):
     overwrite that tensor.  torch routes only the recording thread's allocations to the pool (torch.cuda.use_mem_pool),
     so the allocation is made on a helper thread; it is rare (first use, growth).  `filled_on` = the device to
     synchronise when `make` also launches fills (they run on the helper thread's stream)."""
-    if not _lib._recorders or getattr(_lib._rec_tls, "rec", None) is None:
+    if getattr(_lib._rec_tls, "rec", None) is None:
         return make()
     import threading
     box = []

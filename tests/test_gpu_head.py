@@ -225,3 +225,39 @@ def test_tmsu_uncertainty_loss_train_step():
     params = dict(m.backbone.named_parameters())
     for k in ("endconv.weight", "DeBlock2.conv2.weight", "EnBlock1.conv1.weight"):
         assert l2_rel_err(params[k].grad, sd[k].grad) < GRAD_L2_TOL, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_k4_fast_path_honours_the_sample_stride(dtype):
+    """The C ABI takes explicit strides: K=4 channels-last logits whose sample stride is larger than 4 V (a padded
+    batch buffer) must give the contiguous call's loss sums and gradient, through the straight-line K=4 kernels
+    (k_dce4_*), and leave the padding alone (they indexed samples as n*V*4)."""
+    import ctypes as C
+    from devis_amd import _lib, ops
+    lib = _lib.load()
+    n, v, pad = 3, 1000, 24
+    g = torch.Generator().manual_seed(11)
+    z = (torch.randn((n, v, 4), generator=g) * 3).to(dtype).cuda()
+    lab = torch.randint(0, 4, (n, v), generator=g).cuda()
+    one = torch.ones((), device="cuda")
+    scal_c, ev_c, _ = ops.evid_loss_fwd(z, True, lab, 0.5, True)
+    dz_c = ops.evid_loss_bwd(z, True, lab, 0.5, scal_c, one)
+    zp = torch.full((n, v + pad, 4), 7.0, dtype=dtype, device="cuda")
+    zp[:, :v] = z
+    dzp = torch.full_like(zp, -5.0)
+    sn = (v + pad) * 4
+    scal = torch.empty_like(scal_c)
+    ev = torch.empty_like(ev_c)
+    nb = lib.devis_evid_workspace_bytes(n, v, 4)
+    ws = ops.workspace(nb, z.device)
+    st = torch.cuda.current_stream().cuda_stream
+    dt = _lib.DEVIS_F32 if dtype == torch.float32 else _lib.DEVIS_BF16
+    _lib.check(lib.devis_evid_loss_fwd(zp.data_ptr(), sn, 4, 1, dt, lab.data_ptr(), _lib.LABEL_I64, n, v, 4, C.c_float(0.5),
+                                       ev.data_ptr(), None, scal.data_ptr(), ws.data_ptr(), nb, st), "fwd")
+    _lib.check(lib.devis_evid_loss_bwd(zp.data_ptr(), sn, 4, 1, dt, lab.data_ptr(), _lib.LABEL_I64, n, v, 4, C.c_float(0.5),
+                                       scal.data_ptr(), one.data_ptr(), None, None, None, dzp.data_ptr(), st), "bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(scal, scal_c)
+    assert torch.equal(ev, ev_c)
+    assert torch.equal(dzp[:, :v], dz_c)
+    assert (dzp[:, v:] == -5.0).all()

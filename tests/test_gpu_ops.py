@@ -499,3 +499,25 @@ def test_conv_dgrad_with_norm_backward_prologue(shape, variant):
     assert torch.equal(dx, dx_ref)
     if norm is not None:
         assert part[1] == part_ref[1] and torch.equal(part[0], part_ref[0])
+
+
+@pytest.mark.parametrize("kernel,pad", [((1, 1, 1), (0, 0, 0)), ((5, 5, 5), (2, 2, 2)), ((3, 3, 3), (1, 1, 1))])
+def test_conv_dgrad_normbwd_refuses_other_geometries(kernel, pad):
+    """devis_conv_dgrad_normbwd runs a 27-tap pad-1 kernel: a 16->16 stride-1 layer of any other kernel size keeps
+    the spatial shape too and must come back as DEVIS_ERR_UNSUPPORTED (-2) through the raw C ABI, before any launch
+    (ADVICE r2); the 3x3x3 descriptor on the same buffers is accepted."""
+    import ctypes as C
+    from devis_amd import _lib, ops
+    lib = _lib.load()
+    n, d, h, w = 1, 4, 8, 32
+    z = lambda *s: torch.zeros(s, device="cuda")
+    g = torch.zeros((n, d, h, w, 16), dtype=torch.bfloat16, device="cuda")
+    xn, dx, dh = torch.zeros_like(g), torch.zeros_like(g), torch.zeros_like(g)
+    wd = torch.zeros((16, 27, 16), dtype=torch.bfloat16, device="cuda")
+    sc, sh, ca, cb, cc = z(n, 16), z(n, 16), z(n, 16), z(n, 16), z(n, 16)
+    desc = ops.ConvGeom(kernel, (1, 1, 1), pad).desc(n, (d, h, w), 16, 0, 16, torch.bfloat16)
+    rc = lib.devis_conv_dgrad_normbwd(C.byref(desc), g.data_ptr(), xn.data_ptr(), sc.data_ptr(), sh.data_ptr(), ca.data_ptr(),
+                                      cb.data_ptr(), cc.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), dh.data_ptr(), None,
+                                      torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == (0 if kernel == (3, 3, 3) else -2)

@@ -68,7 +68,8 @@ def test_noalloc_entry_runs_with_the_allocator_untouched():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert torch.cuda.memory_stats()["allocation.all.allocated"] == a0
-    assert free1 == free0
+    # the driver's figure is device-wide (other processes, lazily loaded code objects move it): a coarse check only
+    assert free1 >= free0 - (8 << 20)
 
 
 def test_noalloc_entry_refuses_more_samples_than_its_scratch_holds():
