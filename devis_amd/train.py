@@ -1,6 +1,11 @@
 """Train / val drivers with the call surface of the reference's trainUMIS.py (train :239, val :265,
-adjust_learning_rate :217, AverageMeter :221, getArgs :35).  Data loaders are the caller's: anything
-yielding (input NC(D)HW fp32, target) batches works; the tensor work runs on the HIP kernels.
+adjust_learning_rate :217, AverageMeter :221, getArgs :35) and its entry point (`__main__` :1357-1449):
+
+    python -m devis_amd.train --dataset BraTS --mode train --synthetic 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m devis_amd.train ...
+
+Data loaders are the caller's (`run(args, loaders)`): anything yielding (input NC(D)HW fp32, target) batches
+works; `--synthetic` supplies seeded tensors of the dataset's shapes.  The tensor work runs on the HIP kernels.
 PNG / NIfTI dumps and the medpy metrics of the reference's test() are out of scope.
 """
 from __future__ import annotations
@@ -22,6 +27,7 @@ def getArgs(argv=None):
     p.add_argument('--user', default='name of user', type=str)
     p.add_argument('--experiment', default='UMIS', type=str)
     p.add_argument('--date', default=local_time.split(' ')[0], type=str)
+    p.add_argument('--description', default='Trustworthy medical image segmentation by coco,training on train.txt!', type=str)
     p.add_argument('--start_epoch', type=int, default=1)
     p.add_argument('--end_epochs', type=int, default=99)
     p.add_argument('--submission', default='./results', type=str)
@@ -53,6 +59,12 @@ def getArgs(argv=None):
     p.add_argument('--compute_dtype', default='bf16', choices=['bf16', 'fp32'])
     # not in the reference: spread the eight BraTS patches of a val/test volume over the ranks (same volume on every rank)
     p.add_argument('--shard_patches', action='store_true')
+    # not in the reference (its getDataset reads files from fixed E:/ paths; data loading is out of scope here):
+    # seeded synthetic tensors of the dataset's shapes, this many training batches per epoch / volumes per val, test
+    p.add_argument('--synthetic', type=int, default=0)
+    p.add_argument('--synthetic_val', type=int, default=1)
+    p.add_argument('--seed', type=int, default=1234, help='data seed; rank r draws from seed + r')
+    p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='torch.distributed backend under torchrun')
     args = p.parse_args(argv)
     args.compute_dtype = torch.bfloat16 if args.compute_dtype == 'bf16' else torch.float32
     apply_dataset_overrides(args)
@@ -247,6 +259,12 @@ def selection_dice(conf, dataset):
     return dice_isic_from_counts(conf)
 
 
+def _class_indices(target):
+    """The 2-D loaders hand over float {0..K-1} masks (ts.ToTensor(), data/transform.py:234); the reference compares them
+    with the argmax as they are, the count kernels take integer class indices."""
+    return target if target.dtype in (torch.int64, torch.int32, torch.uint8) else target.to(torch.int64)
+
+
 def val(args, model, current_epoch, best_dice, valid_loader, save=True):
     """trainUMIS.py:265-331: argmax(alpha/S), the dataset's selection dice (`selection_dice`), checkpoint
     {'epoch','state_dict'} with the reference's file name and trigger rule (:314-330).  In a process group only
@@ -260,6 +278,7 @@ def val(args, model, current_epoch, best_dice, valid_loader, save=True):
             target = target[..., :155]
         out = predict_volume(model, x, args.dataset, graph_streams=getattr(args, 'graph_streams', 0),
                              shard=getattr(args, 'shard_patches', False))
+        target = _class_indices(target)
         conf = ops.eval_counts(out["pred"].reshape(-1), target.reshape(-1).contiguous(), args.num_classes)["conf"]
         dice_total += selection_dice(conf.cpu().numpy(), args.dataset)
     aver_dice = dice_total / max(1, len(valid_loader))
@@ -334,6 +353,7 @@ def test(args, model, test_loader, log=print):
         torch.cuda.synchronize()
         runtimes.append(time.time() - t0)
         n += 1
+        target = _class_indices(target)
         for c, out in outs.items():
             r = evaluate_volume(out, target, k, len(UEO_THRESHOLDS))
             dice, iou = _region_scores(r['conf'], args.dataset, k)
@@ -354,3 +374,169 @@ def test(args, model, test_loader, log=print):
     res['regions'] = _REGIONS.get(args.dataset)
     res['runtime'] = float(np.mean(runtimes)) if runtimes else 0.0
     return res
+
+
+# ------------------------------------------------------------------ entry point (trainUMIS.py:1357-1449)
+_IN_CHANNELS = {'BraTS': 4, 'LiTS': 1, 'ISIC': 3, 'DRIVE': 3, 'TOAR': 1, 'HC': 1}       # what TMSU's backbones take
+OOD_CONDITIONS = ('noise', 'blur', 'mask')                                              # trainUMIS.py:1404
+
+
+def _in_channels(args):
+    if args.model_name == 'V' and args.dataset not in ('BraTS', 'LiTS'):
+        return 3                                   # VNet2D(n_channels=3) on every 2-D dataset, TrustworthySeg.py:54,78,91,104
+    return _IN_CHANNELS[args.dataset]
+
+
+class SyntheticLoader:
+    """`n` seeded batches shaped like the dataset's: x fp32 N(C)(D)HW, target int64 (3-D: N,D,H,W
+    - BraTS crops, data/BraTS2019.py:46-57,135-146) or float {0..K-1} (2-D: N,1,H,W as ts.ToTensor() leaves it,
+    data/transform.py:234); with `noised`, (x, x + 0.1 * noise, target) like the reference's test loaders.  The batches
+    are drawn once on the CPU generator and live on the host, as a DataLoader's would."""
+
+    def __init__(self, n, batch, channels, spatial, classes, seed, noised=False):
+        g = torch.Generator().manual_seed(seed)
+        self.items = []
+        for _ in range(n):
+            x = torch.randn((batch, channels) + tuple(spatial), generator=g)
+            if len(spatial) == 3:
+                y = torch.randint(0, classes, (batch,) + tuple(spatial), generator=g)
+            else:
+                y = torch.randint(0, classes, (batch, 1) + tuple(spatial), generator=g).float()
+            if noised:
+                self.items.append((x, x + 0.1 * torch.randn(x.shape, generator=g), y))
+            else:
+                self.items.append((x, y))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __iter__(self):
+        return iter(self.items)
+
+
+def synthetic_loaders(args, rank=0, salt=0):
+    """(train, valid, test) loaders of seeded tensors: training batches of `batch_size` crops (BraTS: crop_H x crop_W x
+    crop_D, trainUMIS.py:65-67; otherwise the dataset's out_size), validation / test volumes of batch 1 at the full
+    size (BraTS: input_H x input_W x input_D = 240 x 240 x 160, which tailor_and_concat's fixed crops need).  Rank r
+    draws its TRAINING data from seed + r; validation / test volumes are the same on every rank."""
+    c, k = _in_channels(args), args.num_classes
+    if args.dataset == 'BraTS':
+        crop = (args.crop_H, args.crop_W, args.crop_D)
+        full = (args.input_H, args.input_W, args.input_D)
+    else:
+        crop = full = tuple(args.out_size)
+    seed = args.seed + 7919 * salt
+    train_loader = SyntheticLoader(args.synthetic, args.batch_size, c, crop, k, seed + rank)
+    valid_loader = SyntheticLoader(args.synthetic_val, 1, c, full, k, seed + 100003)
+    test_loader = SyntheticLoader(args.synthetic_val, 1, c, full, k, seed + 200003, noised=True)
+    return train_loader, valid_loader, test_loader
+
+
+def init_distributed(args):
+    """Under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment): one process per GPU, the process group
+    created BEFORE any GPU work with RCCL's stream taken from the high-priority pool (parallel.nccl_options: it
+    must not share the main stream's hardware queue).  -> (rank, world, device)."""
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
+    if not torch.cuda.is_available():
+        raise SystemExit("devis_amd.train needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if "RANK" in os.environ:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            if args.backend == 'nccl':
+                from .parallel import nccl_options
+                dist.init_process_group("nccl", device_id=dev, pg_options=nccl_options())
+            else:
+                dist.init_process_group("gloo")
+    return rank, world, dev
+
+
+def build(args, rank=0):
+    """model, optimizer, reducer as trainUMIS.py:1389-1395 builds them (TMSU, Adam(lr, weight_decay=1e-5)) - the
+    optimizer as the one-launch FusedAdam, identical replicas on every rank (same seed + a broadcast from rank 0), the
+    gradient all-reduce bucketed and overlapped with backward when there is a process group."""
+    import torch.distributed as dist
+    from . import TMSU
+    from .optim import FusedAdam
+    from .parallel import GradientAllReducer, broadcast_parameters
+    torch.manual_seed(0)
+    model = TMSU(args)
+    model.cuda()
+    total = sum(p.nelement() for p in model.parameters())
+    if rank == 0:
+        print("Number of model's Params: %.2fM" % (total / 1e6))
+    on = dist.is_available() and dist.is_initialized()
+    if on:
+        broadcast_parameters(model, 0)
+    optimizer = FusedAdam(model.parameters(), lr=args.lr, weight_decay=1e-5, module=model)
+    reducer = GradientAllReducer(model.parameters(), module=model) if on and dist.get_world_size() > 1 else None
+    return model, optimizer, reducer
+
+
+def run(args, loaders=None, log=print):
+    """The reference's `__main__` after argument parsing (trainUMIS.py:1387-1449): model, Adam, then by `args.mode`
+    'train&test' (epochs start_epoch..end_epochs of train + val, then test), 'train' (epochs 1..end_epochs of train +
+    val) or 'test' (the OOD condition x level sweep of :1436-1446, three levels of 'noise' and 'blur').  `loaders` =
+    (train, valid, test), or a callable(args) returning them (called again per OOD setting like getDataset); None takes
+    the synthetic ones.  -> dict(loss_list, dice_list, best_dice, test)."""
+    mode = args.mode                                 # train() / test() overwrite args.mode like the reference (:252)
+    if mode not in ('train&test', 'train', 'test'):
+        print('There is no this mode')
+        raise NameError(mode)
+    rank, world, _ = init_distributed(args)
+    quiet = (lambda *a, **k: None)
+    say = log if rank == 0 else quiet
+    if loaders is None:
+        if not args.synthetic:
+            raise SystemExit("devis_amd.train: no data - pass --synthetic N (seeded tensors of the dataset's shapes) or "
+                             "call devis_amd.train.run(args, loaders) with your own loaders; the reference's file "
+                             "readers (data/*.py) are outside the scope of this package")
+        get = lambda a, salt=0: synthetic_loaders(a, rank, salt)
+    elif callable(loaders):
+        get = lambda a, salt=0: loaders(a)
+    else:
+        get = lambda a, salt=0: loaders
+    train_loader, valid_loader, test_loader = get(args)
+    model, optimizer, reducer = build(args, rank)
+    out = dict(loss_list=[], dice_list=[], best_dice=0, test=None)
+    best_dice = 0
+    if mode in ('train&test', 'train'):
+        first = args.start_epoch if mode == 'train&test' else 1
+        for epoch in range(first, args.end_epochs + 1):
+            say('===========Train begining!===========')
+            say('Epoch {}/{}'.format(epoch, args.end_epochs - 1))
+            epoch_loss = train(args, model, optimizer, epoch, train_loader, reducer=reducer, log=say)
+            say("epoch %d avg_loss:%0.3f" % (epoch, epoch_loss))
+            _, best_dice = val(args, model, epoch, best_dice, valid_loader)
+            out['loss_list'].append(epoch_loss)
+            out['dice_list'].append(best_dice)
+        if mode == 'train&test':
+            out['test'] = test(args, model, test_loader, log=say)
+    else:
+        out['test'] = {}
+        for j in range(0, 2):
+            args.OOD_Condition = OOD_CONDITIONS[j]
+            say("arg.OOD_Condition: %s" % args.OOD_Condition)
+            for i in range(1, 4):
+                say("arg.OOD_Level: %d" % i)
+                args.OOD_Level = i
+                _, _, test_loader = get(args, 3 * j + i)
+                out['test'][(args.OOD_Condition, i)] = test(args, model, test_loader, log=say)
+    out['best_dice'] = best_dice
+    out['model'] = model
+    return out
+
+
+def main(argv=None):
+    args = getArgs(argv)
+    out = run(args)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -318,28 +318,107 @@ def _offset_cat_drive(skip: Tensor, up: Tensor, rand_log: Optional[List[Tuple[in
 
 
 def unet2d_forward(sd: StateDict, x: Tensor, training: bool = True, drive: bool = False,
-                   rand_log: Optional[List[Tuple[int, ...]]] = None) -> Tensor:
+                   rand_log: Optional[List[Tuple[int, ...]]] = None, taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """Unet2D.forward (UNet2DZoo.py:130-160) / Unet2DDRIVE.forward (:207-237).
 
-    Returns the raw logits ``c10`` (the ``nn.Softmax()`` at :159 is dead code).
+    Returns the raw logits ``c10`` (the ``nn.Softmax()`` at :159 is dead code).  ``taps``: a dict that receives the
+    output of every DoubleConv / ConvTranspose (the per-layer audit of tests/test_gpu_unet2d.py reads it).
     """
     ocat = _offset_cat_drive if drive else _offset_cat_w
-    c1 = _double_conv(sd, "conv1", x, training)
-    c2 = _double_conv(sd, "conv2", F.max_pool2d(c1, 2), training)
-    c3 = _double_conv(sd, "conv3", F.max_pool2d(c2, 2), training)
-    c4 = _double_conv(sd, "conv4", F.max_pool2d(c3, 2), training)
-    c5 = _double_conv(sd, "conv5", F.max_pool2d(c4, 2), training)
+
+    def dc(name: str, t: Tensor) -> Tensor:
+        y = _double_conv(sd, name, t, training)
+        if taps is not None:
+            taps[name] = y
+        return y
+
+    c1 = dc("conv1", x)
+    c2 = dc("conv2", F.max_pool2d(c1, 2))
+    c3 = dc("conv3", F.max_pool2d(c2, 2))
+    c4 = dc("conv4", F.max_pool2d(c3, 2))
+    c5 = dc("conv5", F.max_pool2d(c4, 2))
 
     def up(name: str, t: Tensor) -> Tensor:
-        return F.conv_transpose2d(t, sd[name + ".weight"], sd[name + ".bias"], stride=2)
+        y = F.conv_transpose2d(t, sd[name + ".weight"], sd[name + ".bias"], stride=2)
+        if taps is not None:
+            taps[name] = y
+        return y
 
-    c6 = _double_conv(sd, "conv6", ocat(c4, up("up6", c5), rand_log), training)
-    c7 = _double_conv(sd, "conv7", ocat(c3, up("up7", c6), rand_log), training)
-    c8 = _double_conv(sd, "conv8", torch.cat([up("up8", c7), c2], dim=1), training)
+    c6 = dc("conv6", ocat(c4, up("up6", c5), rand_log))
+    c7 = dc("conv7", ocat(c3, up("up7", c6), rand_log))
+    c8 = dc("conv8", torch.cat([up("up8", c7), c2], dim=1))
     u9 = up("up9", c8)
     m9 = ocat(c1, u9, rand_log) if drive else torch.cat([u9, c1], dim=1)
-    c9 = _double_conv(sd, "conv9", m9, training)
+    c9 = dc("conv9", m9)
     return _conv(sd, "conv10", c9, pad=0)
+
+
+# ---- the same network with a bf16 pipeline's roundings put in (NOT the reference's arithmetic: a measuring stick) ----
+# The reference computes in fp32.  A bf16 tensor-core pipeline must round (i) every weight, (ii) every stored
+# activation and (iii) every matrix operand to bf16; everything between two roundings stays fp32 (accumulators, bias,
+# BatchNorm statistics and affine).  `unet2d_forward_bf16_points` restates Unet2D with exactly those roundings at the
+# points where devis_amd's bf16 path has them (DESIGN.md 4): it separates what the ROUNDING POINTS cost (this function
+# against unet2d_forward - a property of bf16 and of the network's conditioning, the same for any bf16 implementation)
+# from what the KERNELS add on top (devis_amd against this function).
+
+def _q(t: Tensor) -> Tensor:
+    return t.bfloat16().float()
+
+
+def _bn_affine(sd: StateDict, key: str, h: Tensor, training: bool) -> Tuple[Tensor, Tensor]:
+    # BatchNorm as a per-channel (scale, shift) from the statistics of the STORED tensor h (UNet2DZoo.py:12,15)
+    dims = (0, 2, 3)
+    if training:
+        mean = h.double().mean(dims)
+        var = h.double().var(dims, unbiased=False)
+    else:
+        mean, var = sd[key + ".running_mean"].double(), sd[key + ".running_var"].double()
+    scale = sd[key + ".weight"].double() / torch.sqrt(var + 1e-5)
+    shift = sd[key + ".bias"].double() - mean * scale
+    return scale.float().view(1, -1, 1, 1), shift.float().view(1, -1, 1, 1)
+
+
+def unet2d_forward_bf16_points(sd: StateDict, x: Tensor, training: bool = True, drive: bool = False,
+                               taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """Unet2D / Unet2DDRIVE (UNet2DZoo.py:130-160, 207-237) evaluated in fp32 with bf16 roundings of the weights, of
+    every stored tensor (conv / ConvTranspose outputs, BatchNorm+ReLU outputs, logits) and of every conv operand.
+    Does not touch the running statistics in ``sd``.  offsetCat's torch.rand padding is drawn like the reference's."""
+    ocat = _offset_cat_drive if drive else _offset_cat_w
+
+    def conv(key: str, t: Tensor, pad: int = 1) -> Tensor:
+        return _q(F.conv2d(t, _q(sd[key + ".weight"]), sd[key + ".bias"], padding=pad))
+
+    def dc(name: str, t: Tensor) -> Tensor:
+        h1 = conv(name + ".conv.0", t)
+        sc, sh = _bn_affine(sd, name + ".conv.1", h1, training)
+        a = _q(F.relu(torch.addcmul(sh, h1, sc)))                  # the second conv's operand
+        h2 = conv(name + ".conv.3", a)
+        sc, sh = _bn_affine(sd, name + ".conv.4", h2, training)
+        y = _q(F.relu(torch.addcmul(sh, h2, sc)))
+        if taps is not None:
+            taps[name] = y
+        return y
+
+    def up(name: str, t: Tensor) -> Tensor:
+        y = _q(F.conv_transpose2d(t, _q(sd[name + ".weight"]), sd[name + ".bias"], stride=2))
+        if taps is not None:
+            taps[name] = y
+        return y
+
+    def cat_q(skip: Tensor, u: Tensor) -> Tensor:
+        return _q(ocat(skip, u, None))                             # rounds the torch.rand padding; the rest is bf16 already
+
+    c1 = dc("conv1", _q(x))
+    c2 = dc("conv2", F.max_pool2d(c1, 2))
+    c3 = dc("conv3", F.max_pool2d(c2, 2))
+    c4 = dc("conv4", F.max_pool2d(c3, 2))
+    c5 = dc("conv5", F.max_pool2d(c4, 2))
+    c6 = dc("conv6", cat_q(c4, up("up6", c5)))
+    c7 = dc("conv7", cat_q(c3, up("up7", c6)))
+    c8 = dc("conv8", torch.cat([up("up8", c7), c2], dim=1))
+    u9 = up("up9", c8)
+    c9 = dc("conv9", cat_q(c1, u9) if drive else torch.cat([u9, c1], dim=1))
+    return conv("conv10", c9, pad=0)
 
 
 # ----------------------------------------------------------------------------

@@ -5,6 +5,7 @@ import argparse
 
 import numpy as np
 import pytest
+import torch
 
 
 @pytest.mark.parametrize("dataset,classes,out_size", [
@@ -60,3 +61,57 @@ def test_stream_override_is_thread_local():
         t.join()
     assert seen["other"] is None
     assert getattr(ops._tls, "override", None) is None
+
+
+def test_entry_point_parses_every_reference_flag():
+    """`python -m devis_amd.train` takes the reference's command line (trainUMIS.py:35-91): every flag with a
+    non-default value lands under the reference's attribute name, and the defaults are the reference's."""
+    from devis_amd.train import getArgs
+    a = getArgs(['--user', 'u', '--experiment', 'E', '--date', '2020-01-01', '--description', 'd', '--start_epoch', '3',
+                 '--end_epochs', '7', '--submission', 's', '--lambda-epochs', '9', '--save_freq', '2', '--lr', '0.0002',
+                 '--savepath', 'sp', '--save_dir', 'sd', '--mode', 'train', '--dataset', 'ISIC', '--folder', 'folder3',
+                 '--input_H', '1', '--input_W', '2', '--input_D', '3', '--crop_H', '4', '--crop_W', '5', '--crop_D', '6',
+                 '--output_D', '7', '--batch_size', '4', '--OOD_Condition', 'blur', '--OOD_Level', '2', '--snapshot', '',
+                 '--Uncertainty_Loss', 'True', '--input_modality', 't1', '--model_name', 'V', '--test_epoch', '11'])
+    want = dict(user='u', experiment='E', date='2020-01-01', description='d', start_epoch=3, end_epochs=7, submission='s',
+                lambda_epochs=9, save_freq=2, lr=0.0002, savepath='sp', save_dir='sd', mode='train', dataset='ISIC',
+                folder='folder3', input_H=1, input_W=2, input_D=3, crop_H=4, crop_W=5, crop_D=6, output_D=7, batch_size=4,
+                OOD_Condition='blur', OOD_Level=2, snapshot=False, Uncertainty_Loss=True, input_modality='t1',
+                model_name='V', test_epoch=11, num_classes=2, out_size=(224, 300))
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    d = getArgs([])
+    ref = dict(start_epoch=1, end_epochs=99, lambda_epochs=50, lr=0.002, mode='train&test', dataset='LiTS', folder='folder0',
+               input_H=240, input_W=240, input_D=160, crop_H=128, crop_W=128, crop_D=128, output_D=155, batch_size=8,
+               OOD_Condition='normal', OOD_Level=1, snapshot=True, Uncertainty_Loss=False, input_modality='four',
+               model_name='U', test_epoch=199, save_dir='./results', num_classes=3)
+    for k, v in ref.items():
+        assert getattr(d, k) == v, k
+    assert getArgs(['--dataset', 'BraTS', '--batch_size', '8']).batch_size == 2      # trainUMIS.py:1360
+
+
+def test_synthetic_loaders_follow_the_dataset_shapes_and_rank_seeds():
+    from devis_amd.train import getArgs, synthetic_loaders
+    a = getArgs(['--dataset', 'BraTS', '--synthetic', '2', '--crop_H', '16', '--crop_W', '16', '--crop_D', '16',
+                 '--input_H', '24', '--input_W', '24', '--input_D', '16'])
+    tr0, va0, te0 = synthetic_loaders(a, rank=0)
+    tr1, va1, _ = synthetic_loaders(a, rank=1)
+    assert len(tr0) == 2 and len(va0) == 1 and len(te0) == 1
+    x, y = next(iter(tr0))
+    assert x.shape == (2, 4, 16, 16, 16) and x.dtype == torch.float32
+    assert y.shape == (2, 16, 16, 16) and y.dtype == torch.int64 and int(y.max()) <= 3
+    assert not torch.equal(x, next(iter(tr1))[0])                    # rank r trains on seed + r
+    assert torch.equal(next(iter(va0))[0], next(iter(va1))[0])       # every rank validates the same volume
+    xt, xn, yt = next(iter(te0))
+    assert xt.shape == (1, 4, 24, 24, 16) and xn.shape == xt.shape and yt.shape == (1, 24, 24, 16)
+    b = getArgs(['--dataset', 'ISIC', '--synthetic', '1', '--batch_size', '3'])
+    x, y = next(iter(synthetic_loaders(b)[0]))
+    assert x.shape == (3, 3, 224, 300) and y.shape == (3, 1, 224, 300) and y.dtype == torch.float32
+    assert set(y.unique().tolist()) <= {0.0, 1.0}
+
+
+def test_entry_point_refuses_an_unknown_mode_like_the_reference():
+    from devis_amd.train import getArgs, run
+    a = getArgs(['--dataset', 'BraTS', '--mode', 'nonsense', '--synthetic', '1'])
+    with pytest.raises(NameError):                                   # trainUMIS.py:1447-1449
+        run(a)

@@ -257,7 +257,7 @@ def test_k4_fast_path_honours_the_sample_stride(dtype):
     _lib.check(lib.devis_evid_loss_bwd(zp.data_ptr(), sn, 4, 1, dt, lab.data_ptr(), _lib.LABEL_I64, n, v, 4, C.c_float(0.5),
                                        scal.data_ptr(), one.data_ptr(), None, None, None, dzp.data_ptr(), st), "bwd")
     torch.cuda.synchronize()
-    assert torch.equal(scal, scal_c)
+    assert torch.equal(scal[:16], scal_c[:16])          # 4 scalars + I_k, P_k, R_k of K = 4; the rest is never written
     assert torch.equal(ev, ev_c)
     assert torch.equal(dzp[:, :v], dz_c)
     assert (dzp[:, v:] == -5.0).all()

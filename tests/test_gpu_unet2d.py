@@ -3,7 +3,7 @@ including the torch.rand skip padding drawn from the global CPU generator (UNet2
 import pytest
 import torch
 
-from tests.util import BF16_BAR, BF16_MAX_EXCEPTION, FP32_BAR, GRAD_L2_TOL, GRAD_MAX_TOL, LOSS_BF16_BAR, check, l2_rel_err, rel_err, sd_hash
+from tests.util import BF16_BAR, BF16_MAX_EXCEPTION, BF16_OVER_ROUNDING_POINTS, FP32_BAR, GRAD_L2_TOL, GRAD_MAX_TOL, LOSS_BF16_BAR, check, l2_rel_err, rel_err, sd_hash
 
 pytestmark = pytest.mark.gpu
 
@@ -131,3 +131,24 @@ def test_full_size_config2_train_step_vs_oracle_live():
         assert sorted(params) == sorted(names)
         norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
         check(np.max((np.abs(norms - ref) - gatol * ref.max()) / (ref + 1e-30)), gtol, "grad norms %s" % dtype)
+
+
+def test_bf16_error_is_what_the_rounding_points_cost_layer_by_layer():
+    """configs[1] in bf16 misses north_star's 1e-2 on the logits (2.0e-2).  This test pins down WHY, so that the
+    relaxed caps of tests/util.py are a measured property of bf16 on this network and not slack in the kernels: the
+    fp32 oracle with bf16 roundings put in at the points where any bf16 pipeline has them (weights, stored tensors, conv
+    operands: oracle.unet2d_forward_bf16_points) is as far from the fp32 oracle as devis_amd's bf16 path is - after
+    every DoubleConv and ConvTranspose, and at the logits."""
+    import os
+    from tools.bf16_layer_audit import audit, fmt
+    rows = audit(16, 256)
+    text = fmt(rows, 16, 256)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "bf16_layer_audit.txt"), "w") as f:
+        f.write(text + "\n")
+    for name, ours_l2, pts_l2, diff_l2, ours_mx, pts_mx, diff_mx in rows:
+        check(ours_l2 / pts_l2, BF16_OVER_ROUNDING_POINTS, "L2 ours / rounding points, " + name)
+        check(ours_mx / pts_mx, 1.25, "max-norm ours / rounding points, " + name)       # one worst element: noisier
+        check(diff_l2, max(0.5 * pts_l2, 1e-3), "ours vs rounding-point oracle, " + name)
+    logits = rows[-1]
+    check(logits[2], BF16_MAX_EXCEPTION["2D_L2"], "rounding points alone, logits L2 (recorded)")

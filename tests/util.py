@@ -64,10 +64,14 @@ LOSS_BF16_BAR = 1e-3
 # (5.0e-3 at full size, 5.8e-3 on the goldens); the deeper / un-normalised-skip backbones do not in the worst voxel:
 #   AttUnet 1.08e-2 (full size) - three more bf16 BatchNorm + sigmoid gates per skip
 #   V-Net   2.2e-2 (full size), 1.6e-2 (golden) - additive skips carry un-normalised bf16 sums through nine stages
-#   2-D U-Nets 2.3e-2 (16 x 256^2), 1.7e-2 (golden), 1.6e-2 (ISIC 224 x 300) - 23 conv layers, each rounding its
-#     weights and its output to bf16 once (2^-9 each): sqrt(46) * 2^-9 = 1.3e-2 is what uncorrelated roundings alone
-#     give, so the LOGITS of these nets sit at 1.7e-2 (golden) / 2.0e-2 (16 x 256^2) in L2 as well ("2D_L2"); the
-#     evidence of the same runs (what the loss and u consume) is within 1e-2 in L2 (asserted)
+#   2-D U-Nets 2.3e-2 (16 x 256^2), 1.7e-2 (golden), 1.6e-2 (ISIC 224 x 300); their LOGITS 2.0e-2 in L2 as well ("2D_L2").
+#     r03 audit (tools/bf16_layer_audit.py, profiles/r03_bf16_layer_audit.txt): the fp32 oracle with bf16 roundings put
+#     in at the points where any bf16 tensor-core pipeline has them (oracle.unet2d_forward_bf16_points) differs from the
+#     fp32 oracle by the SAME amount at every layer (5.3e-3 after conv1 ... 5.5e-2 after conv5 ... 1.99e-2 at the logits,
+#     equal to ours to four digits); rounding the weights alone costs 9.6e-3.  So these caps are what bf16 costs in this
+#     23-layer network without residual paths, and tests/test_gpu_unet2d.py asserts, layer by layer, that the kernels
+#     add nothing on top (ours-vs-fp32 <= 1.05 x points-vs-fp32).  The evidence of the same runs (what the loss and u
+#     consume) is within 1e-2 in L2 (asserted).
 BF16_MAX_EXCEPTION = {"AU": 1.5e-2, "V": 3e-2, "2D": 3e-2, "2D_L2": 2.5e-2}
 PARITY_LOG = {}
 
@@ -100,3 +104,7 @@ def bf16_ulps(y, ref, slack=1e-5):
     ulp = torch.pow(torch.tensor(2.0, dtype=torch.float64), (e - 8).double())
     excess = ((y - ref).abs() - slack * ref.abs().max()).clamp_min(0.0)
     return (excess / ulp).max().item()
+
+
+# the kernels may add this much to what the bf16 rounding points themselves cost (tests/test_gpu_unet2d.py audit)
+BF16_OVER_ROUNDING_POINTS = 1.05
