@@ -52,6 +52,14 @@ size_t conv_wgrad_mfma_workspace(const devis_conv_desc*);
 int conv_wgrad_mfma(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
                     float*, float*, void*, size_t, hipStream_t);
 
+// bf16 weights of a 27-tap layer with Cin == Cout in {64, 128} are packed in fragment order (csrc/layout.hip), which
+// only conv3_deepk reads: such a layer must never reach a kernel that expects the canonical [Cout][T][Cin] array
+static bool deepk_weights(const devis_conv_desc* d) {
+  return d->dtype == DEVIS_BF16 && d->KD * d->KH * d->KW == 27 && d->C2 == 0 && d->C1 == d->Cout && (d->C1 == 64 || d->C1 == 128);
+}
+
+extern thread_local bool g_wgrad_stage1_only;   // conv_wgrad_mfma.hip
+
 static bool conv_desc_ok(const devis_conv_desc* d) {
   if (!d) return false;
   if (d->N <= 0 || d->ID <= 0 || d->IH <= 0 || d->IW <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0) return false;
@@ -123,6 +131,7 @@ int devis_conv_fwd_stats(const devis_conv_desc* d, const void* x1, const void* x
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   rc = conv_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, &st, nullptr, s);
+  if (rc == DEVIS_ERR_UNSUPPORTED && deepk_weights(d)) return rc;
   if (rc == DEVIS_ERR_UNSUPPORTED) rc = conv2d_fwd_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;      // statistics only come from the MFMA kernels
   if (!in_scale) {
@@ -153,7 +162,7 @@ int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void*
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   rc = conv_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
-  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  if (rc != DEVIS_ERR_UNSUPPORTED || deepk_weights(d)) return rc;
   rc = conv2d_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = head_dgrad(d, dy, w, residual, dx1, &st, nullptr, s);
@@ -221,6 +230,18 @@ int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, c
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
   return conv_wgrad_direct(d, x1, x2, in_scale, in_shift, dy, dw, dbias, s);
+}
+
+int devis_conv_wgrad_stage1(const devis_conv_desc* d, const void* x1, const float* in_scale, const float* in_shift,
+                            const void* dy, int want_bias, void* ws, size_t ws_bytes, void* stream) {
+  if (!conv_desc_ok(d) || !x1 || !dy || !ws || d->C2 != 0) return DEVIS_ERR_BAD_ARG;
+  if ((in_scale != nullptr) != (in_shift != nullptr)) return DEVIS_ERR_BAD_ARG;
+  // the partial-sum kernels never touch dw / dbias (only their second stage does): the workspace stands in for them
+  g_wgrad_stage1_only = true;
+  const int rc = conv_wgrad_mfma(d, x1, nullptr, in_scale, in_shift, dy, (float*)ws, want_bias ? (float*)ws : nullptr, ws, ws_bytes,
+                                 (hipStream_t)stream);
+  g_wgrad_stage1_only = false;
+  return rc;
 }
 
 }  // extern "C"

@@ -324,9 +324,8 @@ static int launch_conv3(const devis_conv_desc* d, const void* x, const void* w, 
 int conv3_c16_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
                     const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
 
-int conv3_deep(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
-               const float* sh, const void* res, void* y, const StatsArgs* st, int64_t* plan_chunks, hipStream_t s);
-int conv3_deep2(const devis_conv_desc*, const void*, const void*, const float*, const float*, const float*, const void*, void*,
+// conv_deepk.hip: the 64- / 128-channel layers, weights stationary in registers and K split over the waves
+int conv3_deepk(const devis_conv_desc*, const void*, const void*, const float*, const float*, const float*, const void*, void*,
                 const StatsArgs*, int64_t*, hipStream_t);
 
 int conv3_c32_march(const devis_conv_desc* d, const void* x, const void* w, const float* bias, const float* sc,
@@ -356,18 +355,13 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
   if (st_ == 1) {
     static const bool no_march = getenv("DEVIS_NO_MARCH") != nullptr;
     if (!no_march && co == 16 && (ci == 16 || (ci == 4 && !sc))) return conv3_c16_march(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
-    static const bool no_deep = getenv("DEVIS_NO_DEEP") != nullptr;
-    // DEVIS_DEEP2: bit 0 = 64-channel layers, bit 1 = 128-channel layers on conv_deep64.hip's kernel (default: 64 only)
-    static const int deep2 = getenv("DEVIS_DEEP2") ? atoi(getenv("DEVIS_DEEP2")) : 1;
-    if (!no_deep && ci == co && ((ci == 64 && (deep2 & 1)) || (ci == 128 && (deep2 & 2)))) return conv3_deep2(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
-    if (!no_deep && ci == co && (ci == 64 || ci == 128)) return conv3_deep(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
+    // 64 / 128 channels: their packed weights are in fragment order (csrc/layout.hip), which only this kernel reads
+    if (ci == co && (ci == 64 || ci == 128)) return conv3_deepk(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
     if (ci == 16 && co == 16) return CONV3(16, 16, 8, 8, 16, 1);
     if (ci == 4 && co == 16 && !sc) return CONV3(16, 16, 8, 8, 16, 1);
     static const bool no_march32 = getenv("DEVIS_NO_MARCH32") != nullptr;
     if (!no_march32 && ci == 32 && co == 32) return conv3_c32_march(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
     if (ci == 32 && co == 32) return CONV3(32, 32, 4, 8, 16, 1, 2);
-    if (ci == 64 && co == 64) return CONV3(64, 64, 4, 4, 16, 1);
-    if (ci == 128 && co == 128) return CONV3(128, 32, 2, 4, 16, 1);
   } else if (st_ == 2) {
     // 32 -> 64: the (2,4,16) tile re-reads less halo than (2,2,16): 36 vs 41 us at 64^3 (tools/time_s2_fwd.py);
     // for 16 -> 32 the larger (4,4,16) tile was measured at 145 vs 86 us (one block per CU) and is not built

@@ -208,8 +208,11 @@ k_wgrad3_mfma(WgArgs a) {
 }
 
 // dw[co][ci<cin_real][t] = sum_gx part[gx][t][co][ci];  dbias[co] = sum_gx bpart[gx][co]   (wgrad_reduce.h)
+thread_local bool g_wgrad_stage1_only = false;     // devis_conv_wgrad_stage1 (capi.hip): profiling the first stage alone
+
 int launch_wgrad_reduce(const float* part, const float* bpart, int gx, int Cout, int Cin, int cin_real, float* dw,
                         float* dbias, hipStream_t s) {
+  if (g_wgrad_stage1_only) return DEVIS_OK;
   RedArgs r;
   r.part = part; r.bpart = bpart; r.dw = dw; r.dbias = dbias;
   r.nparts = gx; r.nbparts = gx; r.Cb = Cout;

@@ -26,13 +26,30 @@ __global__ void k_nxc_to_ncx(const T* __restrict__ src, float* __restrict__ dst,
   for (int64_t c = 0; c < C; ++c) d[c * V] = ld(s + c);
 }
 
+// ---- fragment-major layout of the deep 3x3x3 layers (bf16, 27 taps, Cin == Cout in {64, 128}) ----
+// conv_deepk.hip keeps a wave's weights in registers as MFMA A fragments; read from the canonical [row][tap][col]
+// layout each fragment load touches 16 rows x 64 bytes (measured: 67 cycles per wave-instruction, 10 us per launch
+// before the first MFMA).  For these layers every packing call therefore writes fragment order instead: element
+// (row, tap, col) of the canonical array sits at
+//   (((((row / 32) * (C / 32) + col / 32) * 27 + tap) * 2 + (row / 16) % 2) * 64 + ((col / 8) % 4) * 16 + row % 16) * 8 + col % 8
+// i.e. [cout group of 32][32-channel K chunk][tap][cout tile of 16][lane][8 channels]: a wave's 55 KB are contiguous and
+// every fragment load is one 1 KB run.  Only conv3_deepk consumes such weights (devis_conv_fwd / _dgrad refuse any other
+// route for them); include/devis_hip.h states the rule for callers that pack weights themselves.
+__host__ __device__ inline bool deepk_layout(int64_t rows, int64_t cols, int64_t taps, int elem_bytes) {
+  return elem_bytes == 2 && taps == 27 && rows == cols && (rows == 64 || rows == 128);
+}
+__device__ __forceinline__ int64_t deepk_index(int64_t row, int64_t t, int64_t col, int64_t C) {
+  return (((((row >> 5) * (C >> 5) + (col >> 5)) * 27 + t) * 2 + ((row >> 4) & 1)) * 64 + ((col >> 3) & 3) * 16 + (row & 15)) * 8 + (col & 7);
+}
+
 // dst[a][t][b] = src[a][b][t]
 template <typename T>
 __global__ void k_pack_abt(const float* __restrict__ src, T* __restrict__ dst, int64_t A, int64_t B, int64_t Tn) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A * B * Tn) return;
   const int64_t b = i % B, t = (i / B) % Tn, a = i / (B * Tn);
-  st(dst + i, src[(a * B + b) * Tn + t]);
+  const int64_t o = deepk_layout(A, B, Tn, sizeof(T)) ? deepk_index(a, t, b, A) : i;
+  st(dst + o, src[(a * B + b) * Tn + t]);
 }
 // dst[t][co][ci] = src[ci][co][t]
 template <typename T>
@@ -49,7 +66,8 @@ __global__ void k_repack_dgrad(const T* __restrict__ src, T* __restrict__ dst, i
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Cout * Cin * Tn) return;
   const int64_t co = i % Cout, tf = (i / Cout) % Tn, ci = i / (Cout * Tn);
-  dst[i] = src[(co * Tn + (Tn - 1 - tf)) * Cin + ci];
+  if (deepk_layout(Cout, Cin, Tn, sizeof(T))) dst[deepk_index(ci, tf, co, Cin)] = src[deepk_index(co, Tn - 1 - tf, ci, Cin)];
+  else dst[i] = src[(co * Tn + (Tn - 1 - tf)) * Cin + ci];
 }
 
 // All weights of a model in one launch: block b handles DEVIS_PACK_CHUNK output elements of item
@@ -66,13 +84,16 @@ k_pack_batch(const devis_pack_item* __restrict__ items, const int2* __restrict__
   for (int k = 0; k < DEVIS_PACK_CHUNK / 256; ++k) {
     const int64_t i = (int64_t)ch.y + k * 256 + threadIdx.x;
     if (i >= total) return;
-    int64_t si;
+    int64_t si, di = i;
+    const bool frag = deepk_layout(R, Cc, Tn, sizeof(T));       // the deep 3x3x3 layers: fragment order (above)
     if (it.mode == DEVIS_PACK_CONV) {               // src [co][ci][t] -> dst [co][t][ci]
       const int64_t ci = i % Cc, t = (i / Cc) % Tn, co = i / (Cc * Tn);
       si = (co * Cc + ci) * Tn + t;
+      if (frag) di = deepk_index(co, t, ci, R);
     } else if (it.mode == DEVIS_PACK_CONV_DGRAD) {  // src [co][ci][t] -> dst [ci][T-1-t][co]
       const int64_t co = i % R, tf = (i / R) % Tn, ci = i / (R * Tn);
       si = (co * Cc + ci) * Tn + (Tn - 1 - tf);
+      if (frag) di = deepk_index(ci, tf, co, R);
     } else if (it.mode == DEVIS_PACK_CONVT) {       // src [ci][co][t] -> dst [t][co][ci]
       const int64_t ci = i % R, co = (i / R) % Cc, t = i / (R * Cc);
       si = (ci * Cc + co) * Tn + t;
@@ -80,7 +101,7 @@ k_pack_batch(const devis_pack_item* __restrict__ items, const int2* __restrict__
       const int64_t co = i % Cc, t = (i / Cc) % Tn, ci = i / (Cc * Tn);
       si = (ci * Cc + co) * Tn + t;
     }
-    st(dst + i, it.src[si]);
+    st(dst + di, it.src[si]);
   }
 }
 

@@ -421,6 +421,72 @@ def unet2d_forward_bf16_points(sd: StateDict, x: Tensor, training: bool = True, 
     return conv("conv10", c9, pad=0)
 
 
+# ---- the 3-D U-Net with a bf16 pipeline's roundings put in (a measuring stick like unet2d_forward_bf16_points) ----
+
+def _qs(t: Tensor) -> Tensor:
+    """bf16 rounding with a straight-through gradient: autograd then differentiates the fp32 network at the ROUNDED
+    forward values (its ReLU gates are those of a bf16 forward), while the backward arithmetic itself stays fp32."""
+    return t + (t.bfloat16().float() - t).detach()
+
+
+def unet3d_forward_bf16_points(sd: StateDict, x: Tensor, training: bool = True, fused_upcat: bool = True) -> Tensor:
+    """Unet.forward (UNet3DZoo.py:276-305) in fp32 with bf16 roundings where devis_amd's bf16 path has them: weights,
+    every stored tensor (conv outputs after bias and residual, DeBlock outputs, logits), every conv operand
+    (norm + ReLU outputs).  Norm statistics come from the stored tensors; with `fused_upcat` DeUpCat3 / DeUpCat2 are
+    evaluated as the one-pass form y = W3a prev + (W3b Wt[p]) t + (b3 + W3b bt) with the composite matrices rounded
+    (csrc/upcat.hip), DeUpCat4 layer by layer.  Differentiable (straight-through roundings); running statistics in
+    ``sd`` are not touched."""
+    def conv(key: str, t: Tensor, stride: int = 1, pad: int = 1, res: Optional[Tensor] = None) -> Tensor:
+        y = F.conv3d(t, _qs(sd[key + ".weight"]), sd[key + ".bias"], stride=stride, padding=pad)
+        return _qs(y if res is None else y + res)
+
+    def gn_op(key: str, h: Tensor) -> Tensor:            # GroupNorm(8) + ReLU as the next conv's operand
+        return _qs(F.relu(F.group_norm(h, 8, sd[key + ".weight"], sd[key + ".bias"], 1e-5)))
+
+    def bn(key: str, h: Tensor) -> Tensor:
+        if training:
+            return F.batch_norm(h, None, None, sd[key + ".weight"], sd[key + ".bias"], True, 0.1, 1e-5)
+        return F.batch_norm(h, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"],
+                            sd[key + ".bias"], False, 0.1, 1e-5)
+
+    def en(name: str, t: Tensor) -> Tensor:
+        h = conv(name + ".conv1", gn_op(name + ".bn1", t))
+        return conv(name + ".conv2", gn_op(name + ".bn2", h), res=t)
+
+    def de(name: str, t: Tensor) -> Tensor:
+        h1 = conv(name + ".conv1", t)
+        h2 = conv(name + ".conv2", _qs(F.relu(bn(name + ".bn1", h1))))
+        return _qs(F.relu(bn(name + ".bn2", h2)) + t)
+
+    def upcat(name: str, t: Tensor, prev: Tensor) -> Tensor:
+        c = prev.shape[1]
+        t = conv(name + ".conv1", t, pad=0)
+        w3, b3 = sd[name + ".conv3.weight"], sd[name + ".conv3.bias"]
+        wt, bt = sd[name + ".conv2.weight"], sd[name + ".conv2.bias"]
+        if fused_upcat and c in (16, 32):
+            w3a, w3b = w3[:, :c, 0, 0, 0], w3[:, c:, 0, 0, 0]
+            m = _qs(torch.einsum("om,cmdhw->codhw", w3b, wt))              # composite ConvT weight [c_in][o][2][2][2]
+            bias = b3 + w3b @ bt
+            y = F.conv3d(prev, _qs(w3a)[:, :, None, None, None]) + F.conv_transpose3d(t, m, bias, stride=2)
+            return _qs(y)
+        up = _qs(F.conv_transpose3d(t, _qs(wt), bt, stride=2))
+        return _qs(F.conv3d(torch.cat((prev, up), dim=1), _qs(w3), b3))
+
+    h = conv("InitConv.conv", _qs(x))
+    s1 = en("EnBlock1", h)
+    h = en("EnBlock2_1", conv("EnDown1.conv", s1, stride=2))
+    s2 = en("EnBlock2_2", h)
+    h = en("EnBlock3_1", conv("EnDown2.conv", s2, stride=2))
+    s3 = en("EnBlock3_2", h)
+    h = conv("EnDown3.conv", s3, stride=2)
+    for i in (1, 2, 3, 4):
+        h = en("EnBlock4_%d" % i, h)
+    h = de("DeBlock4", upcat("DeUpCat4", h, s3))
+    h = de("DeBlock3", upcat("DeUpCat3", h, s2))
+    h = de("DeBlock2", upcat("DeUpCat2", h, s1))
+    return conv("endconv", h, pad=0)
+
+
 # ----------------------------------------------------------------------------
 # Evidential criteria  (models/criterions.py)
 # ----------------------------------------------------------------------------

@@ -84,7 +84,10 @@ def test_attunet_train_step_bf16_vs_golden(golden):
     params = dict(m.backbone.named_parameters())
     norms = np.array([params[k].grad.double().norm().item() for k in sorted(params)])
     ref = G[pre + "gradnorm_all"]
-    assert np.all(np.abs(norms - ref) <= 0.08 * ref + 1e-3 * ref.max()), np.max(np.abs(norms - ref) / (ref + 1e-12))
+    # the absolute term covers the conv biases in front of a BatchNorm (W_g.0 / W_x.0 / psi.0): their exact gradient is
+    # zero, the reference's 4e-8 is fp32 summation noise and a bf16 backward leaves bf16 noise there (1.3e-4 measured
+    # for Att2.W_g.0.bias, a sum over 2 M voxels of bf16 gradients, against the largest norm of 0.12)
+    assert np.all(np.abs(norms - ref) <= 0.08 * ref + 2e-3 * ref.max()), np.max(np.abs(norms - ref) / (ref + 1e-12))
 
 
 def test_attunet_matches_oracle_live_with_input_gradient():

@@ -52,6 +52,8 @@ CONV_CASES = [
     (2, 64, 0, 64, (4, 8, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 128, 0, 128, (4, 4, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 128, 0, 128, (2, 2, 2), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 64, 0, 64, (5, 6, 20), (3, 3, 3), (1, 1, 1), (1, 1, 1)),      # weights-stationary kernel (conv_deepk.hip): ragged
+    (2, 128, 0, 128, (3, 5, 18), (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # tiles in D, H and W
     (1, 16, 0, 32, (8, 8, 32), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (2, 32, 0, 64, (8, 8, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (1, 64, 0, 128, (4, 8, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
@@ -316,6 +318,8 @@ STATS_CASES = [
     (2, 32, 32, (5, 9, 24), 1),      # generic 32-channel kernel, ragged
     (2, 64, 64, (4, 8, 16), 1),      # deep 64
     (1, 128, 128, (4, 4, 16), 1),    # deep 128
+    (2, 64, 64, (5, 6, 20), 1),      # deep 64 / 128, ragged tiles (two cout groups per block / four K chunks)
+    (2, 128, 128, (3, 5, 18), 1),
     (1, 16, 32, (8, 8, 32), 2),      # stride-2 (EnDown) variants
     (2, 16, 32, (24, 20, 36), 2),    # stride-2 plane march: several D chunks, ragged tiles
     (2, 32, 64, (18, 12, 40), 2),

@@ -108,3 +108,13 @@ def bf16_ulps(y, ref, slack=1e-5):
 
 # the kernels may add this much to what the bf16 rounding points themselves cost (tests/test_gpu_unet2d.py audit)
 BF16_OVER_ROUNDING_POINTS = 1.05
+
+# End-to-end bf16 gradients, per parameter tensor, L2-relative against the oracle's fp32 autograd.
+# Measured at 2 x 4 x 128^3 (r03, tests/test_gpu_unet3d.py full-size test): worst tensor 25 %, median 5.3 % - while
+# every tensor's NORM agrees to 6.5e-4.  The fp32 oracle with bf16 roundings in its FORWARD only and an exact fp32
+# backward (oracle.unet3d_forward_bf16_points, straight-through roundings) shows the same: worst 24 %, median 5.3 %.
+# Cause: a forward that is 5e-3 off flips the ReLU gate of ~0.2 % of the voxels per layer (pre-activations within the
+# error of zero), each flip moves that voxel's gradient by O(1), and the flips of ~20 layers add up on the way back.
+# Per-element gradient agreement at the 2e-2 level is therefore not a property any bf16 forward has on this network;
+# the test holds the worst and the median tensor to what the rounding points alone cost, times this factor:
+BF16_GRAD_OVER_POINTS = 1.3

@@ -19,7 +19,14 @@ for dtype in (torch.float32, torch.bfloat16):
         if dtype == torch.bfloat16 and kind == "conv":
             co, ci = w.shape[0], w.shape[1]
             t = w.numel() // (co * ci)
-            wd = w.reshape(co, ci, t).flip(2).permute(1, 2, 0).contiguous().to(dtype)
-            bad += int(not torch.equal(views[n][1], wd))
+            # against the forward packing re-packed by devis_repack_conv_weight_dgrad: both are in the layer's own
+            # layout (canonical [Cin][T][Cout], or fragment order for the 64 / 128-channel layers, csrc/layout.hip)
+            wd = torch.empty((ci, t, co), dtype=dtype, device=w.device)
+            from devis_amd import _lib
+            _lib.check(_lib.load().devis_repack_conv_weight_dgrad(ref.data_ptr(), wd.data_ptr(), co, ci, t, _lib.DEVIS_BF16,
+                                                                  torch.cuda.current_stream().cuda_stream), "repack")
+            if not torch.equal(views[n][1], wd):
+                bad += 1
+                print("   dgrad packing differs:", n, tuple(w.shape))
     torch.cuda.synchronize()
     print(dtype, "mismatching packings:", bad, flush=True)
