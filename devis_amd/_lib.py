@@ -80,6 +80,7 @@ SIGNATURES = {
     "devis_repack_conv_weight_dgrad": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
     "devis_conv_wgrad_workspace_bytes": (_SZ, [_CD]),
     "devis_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "devis_conv_wgrad_stage1": (_I, [_CD, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "devis_convT_fwd": (_I, [_CTD, _P, _P, _P, _P, _P]),
     "devis_convT_dgrad": (_I, [_CTD, _P, _P, _P, _P, _P]),
     "devis_convT_wgrad_workspace_bytes": (_SZ, [_CTD]),

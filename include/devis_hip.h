@@ -51,7 +51,15 @@ const char* devis_last_hip_error_string(void);
  * layout of every reference tensor ("fp32 contiguous NCDHW"). */
 int devis_ncx_to_nxc(const float* src, void* dst, int64_t N, int64_t C, int64_t V, int dtype, void* stream);
 int devis_nxc_to_ncx(const void* src, float* dst, int64_t N, int64_t C, int64_t V, int dtype, void* stream);
-/* nn.Conv{2,3}d.weight [Cout][Cin][T] fp32 -> [Cout][T][Cin] dtype */
+/* nn.Conv{2,3}d.weight [Cout][Cin][T] fp32 -> [Cout][T][Cin] dtype.
+ * One exception, the same in every packing call of this header (devis_pack_conv_weight, devis_pack_weights_batch,
+ * devis_repack_conv_weight_dgrad): a bf16 weight with T = 27 and Cin == Cout in {64, 128} - the deep 3x3x3 layers
+ * EnBlock3_x / EnBlock4_x / DeBlock4 of UNet3DZoo.py:35-56,145-165 - is written in FRAGMENT ORDER, the order in which
+ * the kernel of those layers (csrc/conv_deepk.hip) keeps a wave's weights in registers: element (row, tap, col) of
+ * the [rows][T][cols] array sits at
+ *   (((((row/32)*(C/32) + col/32)*27 + tap)*2 + (row/16)%2)*64 + ((col/8)%4)*16 + row%16)*8 + col%8 .
+ * Such a buffer is only meaningful to devis_conv_fwd* / devis_conv_dgrad* of that same layer; a caller that builds
+ * packed weights itself must go through these packing calls.  fp32 weights are never permuted. */
 int devis_pack_conv_weight(const float* w, void* dst, int64_t Cout, int64_t Cin, int64_t T, int dtype, void* stream);
 /* nn.ConvTranspose{2,3}d.weight [Cin][Cout][T] fp32 -> [T][Cout][Cin] dtype */
 int devis_pack_convT_weight(const float* w, void* dst, int64_t Cin, int64_t Cout, int64_t T, int dtype, void* stream);
@@ -151,6 +159,13 @@ size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d);
 int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2,
                      const float* in_scale, const float* in_shift, const void* dy,
                      float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+/* The first stage of devis_conv_wgrad alone, for profiling (no counterpart in the reference): the bf16 MFMA
+ * weight-gradient kernels leave per-block fp32 partial sums in `workspace` (internal layout, sized by
+ * devis_conv_wgrad_workspace_bytes) and the fixed-order reduction that would turn them into dw / dbias is NOT run.
+ * bench.py times the partial-sum kernel by itself with it (roofline line).  One input tensor (C2 = 0);
+ * DEVIS_ERR_UNSUPPORTED for layers the MFMA weight-gradient kernels do not take. */
+int devis_conv_wgrad_stage1(const devis_conv_desc* d, const void* x1, const float* in_scale, const float* in_shift,
+                            const void* dy, int want_bias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ConvTranspose with kernel == stride in every dim (k=2,s=2; 2-D: KD=1).
  * Replaces nn.ConvTranspose3d (UNet3DZoo.py:121) / nn.ConvTranspose2d (UNet2DZoo.py:120-126).
