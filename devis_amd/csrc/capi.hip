@@ -169,11 +169,8 @@ int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void*
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = conv1_dgrad_mfma(d, dy, w_dgrad, residual, dx1, dx2, &st, nullptr, s);
   if (rc != DEVIS_ERR_UNSUPPORTED || st.mode) return rc;     // statistics only come from the MFMA kernels
-  static const bool no_s2lds = getenv("DEVIS_NO_S2LDS") != nullptr;
-  if (!no_s2lds) {
-    rc = conv3s2_dgrad_lds(d, dy, w_dgrad, residual, dx1, s);
-    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
-  }
+  rc = conv3s2_dgrad_lds(d, dy, w_dgrad, residual, dx1, s);
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = conv3s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = conv2s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);

@@ -352,9 +352,6 @@ static int launch_march_s(const devis_conv_desc* d, bool full, dim3 grid, hipStr
 
 // D chunk: enough blocks to fill 256 CUs about twice; each chunk re-reads 2 halo planes
 static int march_dl(int N, int nth, int ntw, int D) {
-  static int dl_env = -1;
-  if (dl_env < 0) { const char* e = getenv("DEVIS_MARCH_DL"); dl_env = e ? atoi(e) : 0; }
-  if (dl_env > 0) return dl_env;
   int dl = 32;
   const int64_t cols = (int64_t)N * nth * ntw;
   while (dl > 8 && cols * cdiv(D, dl) < 512) dl >>= 1;

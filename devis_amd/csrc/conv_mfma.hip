@@ -353,26 +353,19 @@ int conv_fwd_mfma(const devis_conv_desc* d, const void* x1, const void* x2, cons
   const int ci = (int)d->C1, co = (int)d->Cout, st_ = d->SD;
 #define CONV3(...) launch_conv3<__VA_ARGS__>(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s)
   if (st_ == 1) {
-    static const bool no_march = getenv("DEVIS_NO_MARCH") != nullptr;
-    if (!no_march && co == 16 && (ci == 16 || (ci == 4 && !sc))) return conv3_c16_march(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
+    if (co == 16 && (ci == 16 || (ci == 4 && !sc))) return conv3_c16_march(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
     // 64 / 128 channels: their packed weights are in fragment order (csrc/layout.hip), which only this kernel reads
     if (ci == co && (ci == 64 || ci == 128)) return conv3_deepk(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
-    if (ci == 16 && co == 16) return CONV3(16, 16, 8, 8, 16, 1);
-    if (ci == 4 && co == 16 && !sc) return CONV3(16, 16, 8, 8, 16, 1);
-    static const bool no_march32 = getenv("DEVIS_NO_MARCH32") != nullptr;
-    if (!no_march32 && ci == 32 && co == 32) return conv3_c32_march(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
-    if (ci == 32 && co == 32) return CONV3(32, 32, 4, 8, 16, 1, 2);
+    if (ci == 32 && co == 32) return conv3_c32_march(d, x1, w, bias, sc, sh, res, y, st, plan_chunks, s);
   } else if (st_ == 2) {
     // 32 -> 64: the (2,4,16) tile re-reads less halo than (2,2,16): 36 vs 41 us at 64^3 (tools/time_s2_fwd.py);
     // for 16 -> 32 the larger (4,4,16) tile was measured at 145 vs 86 us (one block per CU) and is not built
-    static const bool small32 = getenv("DEVIS_S2_SMALL_TILE") != nullptr;
-    // 16 -> 32 (EnDown1): plane march (conv_s2_march.hip); DEVIS_NO_S2_MARCH=1 keeps the tile kernel (A/B runs)
-    static const bool no_s2_march = getenv("DEVIS_NO_S2_MARCH") != nullptr;
-    if (!no_s2_march && ((ci == 16 && co == 32) || (ci == 32 && co == 64)) && !sc && !res && !(st && st->mode == 2))
+    // 16 -> 32 (EnDown1), 32 -> 64 (EnDown2): plane march (conv_s2_march.hip); with a prologue, a residual or
+    // norm-backward statistics the tile kernel below
+    if (((ci == 16 && co == 32) || (ci == 32 && co == 64)) && !sc && !res && !(st && st->mode == 2))
       return conv3_s2_c16_march(d, x1, w, bias, y, st, plan_chunks, s);
     if (ci == 16 && co == 32) return CONV3(16, 32, 2, 4, 16, 2, 1);
-    if (ci == 32 && co == 64 && !small32) return CONV3(32, 64, 2, 4, 16, 2, 1);
-    if (ci == 32 && co == 64) return CONV3(32, 64, 2, 2, 16, 2, 1);
+    if (ci == 32 && co == 64) return CONV3(32, 64, 2, 4, 16, 2, 1);
     if (ci == 64 && co == 128) return CONV3(64, 64, 2, 2, 16, 2, 1);
   }
 #undef CONV3

@@ -17,6 +17,8 @@
 
 namespace devis {
 
+int launch_wgrad_reduce_frag(const float* part, const float* bpart, int gx, int Cout, int Cin, float* dw, float* dbias,
+                             hipStream_t s);
 int launch_wgrad_reduce(const float* part, const float* bpart, int gx, int Cout, int Cin, int cin_real, float* dw,
                         float* dbias, hipStream_t s);
 
@@ -41,218 +43,10 @@ __device__ __forceinline__ bf16x8 tr_pair_m(const char* p0, const char* p1) {
   return u.v;
 }
 
-template <bool PRO, bool CIN4>
-__global__ void __launch_bounds__(256)
-k_wgrad3_c16_march(WgMarchArgs a) {
-  constexpr int TH = 8, TW = 32;
-  constexpr int HH = TH + 2, HW = TW + 2, HP = HH * HW;
-  constexpr int NPT = (HP * 2 + 255) / 256;          // 16-byte pieces of an x plane per thread (3)
-  constexpr int PLB = NPT * 256 * 16;                // bytes per x plane in LDS
-  constexpr int R = 4;
-  constexpr int YPL = TH * TW * 32;                  // bytes per dy plane tile (2 pieces per thread)
-  constexpr int CINR = CIN4 ? 4 : 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ys = smem + R * PLB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-
-  int tile;
-  {
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int qq = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-    tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
-  }
-  const int twi = tile % a.ntw;
-  const int thi = (tile / a.ntw) % a.nth;
-  const int dci = (tile / (a.ntw * a.nth)) % a.ndc;
-  const int n = tile / (a.ntw * a.nth * a.ndc);
-  const int oh0 = thi * TH, ow0 = twi * TW;
-  const int d0 = dci * a.DL;
-  const int d1 = min(d0 + a.DL, a.D);
-  const size_t plane = (size_t)a.H * a.W;
-
-  // ---- per-thread load slots: x halo plane (3 pieces) and dy plane tile (2 pieces)
-  unsigned goff[NPT];
-  bool ok[NPT];
-  const int piece = tid & 1;
-#pragma unroll
-  for (int k = 0; k < NPT; ++k) {
-    const int i = tid + k * 256;
-    const int u = i >> 1;
-    const int hh = u / HW, hw = u - hh * HW;
-    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
-    ok[k] = i < HP * 2 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && !(CIN4 && piece);
-    goff[k] = ok[k] ? (unsigned)((ih * a.W + iw) * CINR + (CIN4 ? 0 : piece * 8)) : 0u;
-  }
-  unsigned yoff[2];
-  bool yok[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int v = (tid + k * 256) >> 1;               // voxel of the 8x32 tile, row-major
-    const int oh = oh0 + v / TW, ow = ow0 + v % TW;
-    yok[k] = oh < a.H && ow < a.W;
-    yoff[k] = yok[k] ? (unsigned)((oh * a.W + ow) * 16 + piece * 8) : 0u;
-  }
-  float scv[8], shv[8];
-  if (PRO) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      scv[j] = a.sc[n * 16 + piece * 8 + j];
-      shv[j] = a.sh[n * 16 + piece * 8 + j];
-    }
-  }
-  float bsum[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-
-  auto load_x = [&](int id, uint4 (&rg)[NPT]) {
-    const int idc = min(max(id, 0), a.D - 1);
-    const bf16* xp = a.x + ((size_t)n * a.D + idc) * plane * CINR;
-#pragma unroll
-    for (int k = 0; k < NPT; ++k) {
-      if (CIN4) {
-        const uint2 t = *reinterpret_cast<const uint2*>(xp + goff[k]);
-        rg[k] = make_uint4(t.x, t.y, 0u, 0u);
-      } else {
-        rg[k] = *reinterpret_cast<const uint4*>(xp + goff[k]);
-      }
-    }
-  };
-  auto store_x = [&](int id, int slot, uint4 (&rg)[NPT]) {
-    const bool pin = id >= 0 && id < a.D;
-#pragma unroll
-    for (int k = 0; k < NPT; ++k) {
-      uint4 v = rg[k];
-      if (PRO) v = affine_relu8(v, scv, shv);
-      const bool keep = pin && ok[k];
-      v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
-      *reinterpret_cast<uint4*>(smem + slot * PLB + (tid + k * 256) * 16) = v;
-    }
-  };
-  auto load_y = [&](int od, uint4 (&rg)[2]) {
-    const int odc = min(od, a.D - 1);
-    const bf16* yp = a.dy + ((size_t)n * a.D + odc) * plane * 16;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) rg[k] = *reinterpret_cast<const uint4*>(yp + yoff[k]);
-  };
-  auto store_y = [&](int od, int buf, uint4 (&rg)[2]) {
-    const bool pin = od < d1;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      uint4 v = rg[k];
-      const bool keep = pin && yok[k];
-      v.x = keep ? v.x : 0u; v.y = keep ? v.y : 0u; v.z = keep ? v.z : 0u; v.w = keep ? v.w : 0u;
-      bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
-      bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
-      *reinterpret_cast<uint4*>(ys + buf * YPL + (tid + k * 256) * 16) = v;
-    }
-  };
-
-  // ---- fill: x planes d0-1, d0, d0+1 and dy plane d0
-  {
-    uint4 r0[NPT], r1[NPT], r2[NPT], y0[2];
-    load_x(d0 - 1, r0);
-    load_x(d0, r1);
-    load_x(d0 + 1, r2);
-    load_y(d0, y0);
-    store_x(d0 - 1, 0, r0);
-    store_x(d0, 1, r1);
-    store_x(d0 + 1, 2, r2);
-    store_y(d0, 0, y0);
-  }
-  __syncthreads();
-
-  f32x4 acc[7];
-#pragma unroll
-  for (int t = 0; t < 7; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // lane part of the operand addresses: voxel column wv = 4g + q, 8 bytes (4 channels) at p
-  const int wv = 4 * g + q;
-  const int xlane = wv * 32 + p * 8;
-  const int ylane = wv * 32 + p * 8;
-  // this wave's taps: t = wave + 4*tt; in-plane byte offset and kd of each (phantom tap 27 for wave 3 reads tap 26)
-  int toff[7], tkd[7];
-#pragma unroll
-  for (int tt = 0; tt < 7; ++tt) {
-    int t = wave + 4 * tt;
-    if (t > 26) t = 26;
-    tkd[tt] = t / 9;
-    toff[tt] = (((t / 3) % 3) * HW + t % 3) * 32;
-  }
-  const bool last_real = wave + 24 < 27;           // tt = 6 is a real tap for waves 0..2 only
-
-  const int np = d1 - d0;
-  for (int it = 0; it < np; ++it) {
-    const int od = d0 + it;
-    uint4 prex[NPT], prey[2];
-    load_x(od + 2, prex);
-    load_y(od + 1, prey);
-    __builtin_amdgcn_sched_barrier(0);
-
-    const char* yb = ys + (it & 1) * YPL + ylane;
-    int xb[7];
-#pragma unroll
-    for (int tt = 0; tt < 7; ++tt) xb[tt] = ((it + tkd[tt]) & (R - 1)) * PLB + toff[tt] + xlane;
-
-    // K step s = (row pair rp, half h): voxels (2rp, 16h + wv) and (2rp + 1, 16h + wv)
-    auto read_step = [&](int s, bf16x8& af, bf16x8 (&bf)[7]) {
-      const int rp = s >> 1, h = s & 1;
-      const int yo = ((2 * rp) * TW + 16 * h) * 32;
-      af = tr_pair_m(yb + yo, yb + yo + TW * 32);
-      const int xo = ((2 * rp) * HW + 16 * h) * 32;
-#pragma unroll
-      for (int tt = 0; tt < 7; ++tt) bf[tt] = tr_pair_m(smem + xb[tt] + xo, smem + xb[tt] + xo + HW * 32);
-    };
-    bf16x8 afA, afB, bA[7], bB[7];
-    read_step(0, afA, bA);
-#pragma unroll
-    for (int s = 0; s < 8; s += 2) {
-      read_step(s + 1, afB, bB);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tt = 0; tt < 7; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afA, bA[tt], acc[tt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < 8) read_step(s + 2, afA, bA);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tt = 0; tt < 7; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afB, bB[tt], acc[tt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    store_x(od + 2, (it + 3) & (R - 1), prex);
-    store_y(od + 1, (it + 1) & 1, prey);
-    __syncthreads();
-  }
-
-  // ---- partial results: D layout col = ci = lane&15, rows co = (lane>>4)*4 + j
-  float* part = a.part + (size_t)blockIdx.x * 27 * 256;
-#pragma unroll
-  for (int tt = 0; tt < 7; ++tt) {
-    const int t = wave + 4 * tt;
-    if (tt < 6 || last_real) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) part[(t * 16 + g * 4 + j) * 16 + (lane & 15)] = acc[tt][j];
-    }
-  }
-  if (a.bpart) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);       // [256][8]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
-    __syncthreads();
-    if (tid < 16) {
-      const int pc = tid / 8, j = tid % 8;
-      float s = 0.f;
-      for (int k = pc; k < 256; k += 2) s += red[k * 8 + j];
-      a.bpart[(size_t)blockIdx.x * 16 + tid] = s;
-    }
-  }
-}
-
-// ---- K-split variant (the one launched).  In k_wgrad3_c16_march the four waves share the voxels and split the taps,
-// so every wave reads the whole dy tile and 7 shifted x fragments per K step: 16 transposing LDS reads per 7 MFMAs,
-// 32 KB of LDS traffic per 32 voxels and block - the LDS port, not HBM or the matrix pipe, bounds it (55 us of LDS
-// time at 2 x 128^3).  Here the waves split the VOXELS (wave w takes K steps w and w+4 of a plane's 8) and each keeps
+// ---- The waves split the VOXELS.  (The round-1 kernel, deleted in r03, had the four waves share the voxels and split the
+// taps, so every wave read the whole dy tile and 7 shifted x fragments per K step: 16 transposing LDS reads per 7
+// MFMAs, 32 KB of LDS traffic per 32 voxels and block - the LDS port bounded it, 55 us of LDS time at 2 x 128^3.)
+// Here the waves split the VOXELS (wave w takes K steps w and w+4 of a plane's 8) and each keeps
 // all 27 tap accumulators: one dy fragment feeds 27 MFMAs (28 reads per 27 MFMAs, 2.2x less LDS traffic).  The four
 // waves' accumulators are added in wave order through LDS at the end of the walk (once per block).
 template <bool PRO, bool CIN4>
@@ -497,9 +291,6 @@ k_wgrad3_c16_ksplit(WgMarchArgs a) {
 }
 
 static int march_dl(int64_t cols, int D) {
-  static int dl_env = -1;
-  if (dl_env < 0) { const char* e = getenv("DEVIS_WGRAD_DL"); dl_env = e ? atoi(e) : 0; }
-  if (dl_env > 0) return dl_env;
   int dl = 32;
   while (dl > 8 && cols * cdiv(D, dl) < 512) dl >>= 1;
   return dl;
@@ -527,16 +318,9 @@ int wgrad3_c16_march(const devis_conv_desc* d, const void* x, const float* sc, c
   a.part = (float*)ws; a.bpart = dbias ? (float*)((char*)ws + part_bytes) : nullptr;
   constexpr int LDS = 4 * 3 * 256 * 16 + 2 * 8 * 32 * 32;
   const dim3 grid((unsigned)blocks);
-  static const bool tap_split = getenv("DEVIS_WGRAD_C16_TAPSPLIT") != nullptr;      // the round-1 kernel, for A/B runs
-  if (tap_split) {
-    if (d->C1 == 4) hipLaunchKernelGGL((k_wgrad3_c16_march<false, true>), grid, dim3(256), LDS, s, a);
-    else if (sc) hipLaunchKernelGGL((k_wgrad3_c16_march<true, false>), grid, dim3(256), LDS, s, a);
-    else hipLaunchKernelGGL((k_wgrad3_c16_march<false, false>), grid, dim3(256), LDS, s, a);
-  } else {
-    if (d->C1 == 4) hipLaunchKernelGGL((k_wgrad3_c16_ksplit<false, true>), grid, dim3(256), LDS, s, a);
-    else if (sc) hipLaunchKernelGGL((k_wgrad3_c16_ksplit<true, false>), grid, dim3(256), LDS, s, a);
-    else hipLaunchKernelGGL((k_wgrad3_c16_ksplit<false, false>), grid, dim3(256), LDS, s, a);
-  }
+  if (d->C1 == 4) hipLaunchKernelGGL((k_wgrad3_c16_ksplit<false, true>), grid, dim3(256), LDS, s, a);
+  else if (sc) hipLaunchKernelGGL((k_wgrad3_c16_ksplit<true, false>), grid, dim3(256), LDS, s, a);
+  else hipLaunchKernelGGL((k_wgrad3_c16_ksplit<false, false>), grid, dim3(256), LDS, s, a);
   int rc = launch_status();
   if (rc) return rc;
   return launch_wgrad_reduce(a.part, a.bpart, (int)blocks, 16, 16, (int)d->C1, dw, dbias, s);
@@ -573,8 +357,16 @@ __device__ __forceinline__ int img64(int u, int half) { return u * 64 + ((half ^
     __builtin_amdgcn_sched_group_barrier(0x100, n, 0);      \
   }
 
+// r03: PRODUCER / CONSUMER halves.  The r02 kernel ran everything in its four waves, one after the other per plane:
+// issue the next planes' loads (650 cycles), fragments + MFMAs (2.5k), affine + LDS stores (1.1k), barrier - the matrix
+// pipe idle for 40 % of every plane on top of fill and drain (tools/bench_slab.hip).  Now a block has EIGHT waves, two
+// per SIMD: waves 0-3 only read fragments and issue MFMAs (the r02 loop unchanged), waves 4-7 only fetch: each plane's
+// loads are issued two iterations ahead (two register sets), prologue + zero padding + LDS stores + the bias sums run
+// beside the other half's MFMAs (vector and matrix pipes of a SIMD work side by side for two different waves).  The
+// planes' hand-over is still one block barrier per plane.  The partial sums leave in accumulator order (one 16-byte
+// store per lane and tile, 1 KB per wave-instruction instead of four 64-byte rows); the reduction kernel undoes it.
 template <bool PRO>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_wgrad3_slab_march(WgSlabArgs a) {
 #ifdef DEVIS_PHASE_TIMING
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -590,10 +382,13 @@ k_wgrad3_slab_march(WgSlabArgs a) {
   constexpr int YPL = TH * TW * 64;                              // 8 KB per dy plane tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ys = smem + R * PLB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave8 = threadIdx.x >> 6;
+  const bool producer = wave8 >= 4;
+  const int tid = threadIdx.x & 255, wave = wave8 & 3;           // index inside the half
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int nci = a.Cin / 32;
-  const int ci0 = (blockIdx.y % nci) * 32, co0 = (blockIdx.y / nci) * 32;
+  const int slab = blockIdx.y;
+  const int ci0 = (slab % nci) * 32, co0 = (slab / nci) * 32;
 
   int tile;
   {
@@ -608,95 +403,160 @@ k_wgrad3_slab_march(WgSlabArgs a) {
   const int oh0 = thi * TH, ow0 = twi * TW;
   const int d0 = dci * a.DL;
   const int d1 = min(d0 + a.DL, a.D);
+  const int np = d1 - d0;
   const size_t plane = (size_t)a.H * a.W;
-  const int piece = tid & 3;                                      // 8 channels of the slab's 32
 
-  unsigned goff[NPT], loff[NPT];
-  bool ok[NPT];
+  if (producer) {
+    // ------------------------------------------------------------------ waves 4-7: HBM -> LDS
+    const int piece = tid & 3;                                      // 8 channels of the slab's 32
+    unsigned goff[NPT], loff[NPT];
+    bool ok[NPT];
 #pragma unroll
-  for (int k = 0; k < NPT; ++k) {
-    const int i = tid + k * 256;
-    const int u = i >> 2;
-    const int hh = u / HW, hw = u - hh * HW;
-    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
-    ok[k] = i < HP * 4 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-    goff[k] = ok[k] ? (unsigned)((ih * a.W + iw) * a.Cin + ci0 + piece * 8) : (unsigned)ci0;
-    loff[k] = (unsigned)(img64(hh * HWL + hw, piece >> 1) + (piece & 1) * 16);
-  }
-  unsigned yoff[2], yl[2];
-  bool yok[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int v = (tid + k * 256) >> 2;                           // voxel of the 8x16 tile, row-major
-    const int oh = oh0 + v / TW, ow = ow0 + v % TW;
-    yok[k] = oh < a.H && ow < a.W;
-    yoff[k] = yok[k] ? (unsigned)((oh * a.W + ow) * a.Cout + co0 + piece * 8) : (unsigned)co0;
-    yl[k] = (unsigned)(img64(v, piece >> 1) + (piece & 1) * 16);
-  }
-  float scv[8], shv[8];
-  if (PRO) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      scv[j] = a.sc[n * a.Cin + ci0 + piece * 8 + j];
-      shv[j] = a.sh[n * a.Cin + ci0 + piece * 8 + j];
+    for (int k = 0; k < NPT; ++k) {
+      const int i = tid + k * 256;
+      const int u = i >> 2;
+      const int hh = u / HW, hw = u - hh * HW;
+      const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+      ok[k] = i < HP * 4 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+      goff[k] = ok[k] ? (unsigned)((ih * a.W + iw) * a.Cin + ci0 + piece * 8) : (unsigned)ci0;
+      loff[k] = (unsigned)(img64(hh * HWL + hw, piece >> 1) + (piece & 1) * 16);
     }
-  }
-  float bsum[8];
+    unsigned yoff[2], yl[2];
+    bool yok[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-  const bool do_bias = a.bpart != nullptr && ci0 == 0;
+    for (int k = 0; k < 2; ++k) {
+      const int v = (tid + k * 256) >> 2;                           // voxel of the 8x16 tile, row-major
+      const int oh = oh0 + v / TW, ow = ow0 + v % TW;
+      yok[k] = oh < a.H && ow < a.W;
+      yoff[k] = yok[k] ? (unsigned)((oh * a.W + ow) * a.Cout + co0 + piece * 8) : (unsigned)co0;
+      yl[k] = (unsigned)(img64(v, piece >> 1) + (piece & 1) * 16);
+    }
+    float scv[8], shv[8];
+    if (PRO) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        scv[j] = a.sc[n * a.Cin + ci0 + piece * 8 + j];
+        shv[j] = a.sh[n * a.Cin + ci0 + piece * 8 + j];
+      }
+    }
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    const bool do_bias = a.bpart != nullptr && ci0 == 0;
 
-  auto load_x = [&](int id, u32x4 (&rg)[NPT]) __attribute__((always_inline)) {
-    const int idc = min(max(id, 0), a.D - 1);
-    const bf16* xp = a.x + ((size_t)n * a.D + idc) * plane * a.Cin;
+    auto load_x = [&](int id, u32x4 (&rg)[NPT]) __attribute__((always_inline)) {
+      const int idc = min(max(id, 0), a.D - 1);
+      const bf16* xp = a.x + ((size_t)n * a.D + idc) * plane * a.Cin;
 #pragma unroll
-    for (int k = 0; k < NPT; ++k) rg[k] = *reinterpret_cast<const u32x4*>(xp + goff[k]);
-  };
-  auto store_x_piece = [&](int k, int id, int slot, u32x4 (&rg)[NPT]) __attribute__((always_inline)) {
-    const bool pin = id >= 0 && id < a.D;
-    u32x4 v = rg[k];
-    if (PRO) v = affine_relu8(v, scv, shv);
-    if (!(pin && ok[k])) v = (u32x4){0u, 0u, 0u, 0u};
-    if (k < NPT - 1 || tid + k * 256 < HP * 4) *reinterpret_cast<u32x4*>(smem + slot * PLB + loff[k]) = v;
-  };
-  auto store_x = [&](int id, int slot, u32x4 (&rg)[NPT]) __attribute__((always_inline)) {
+      for (int k = 0; k < NPT; ++k) rg[k] = *reinterpret_cast<const u32x4*>(xp + goff[k]);
+    };
+    auto store_x = [&](int id, int slot, u32x4 (&rg)[NPT]) __attribute__((always_inline)) {
+      const bool pin = id >= 0 && id < a.D;
 #pragma unroll
-    for (int k = 0; k < NPT; ++k) store_x_piece(k, id, slot, rg);
-  };
-  auto load_y = [&](int od, u32x4 (&rg)[2]) __attribute__((always_inline)) {
-    const int odc = min(od, a.D - 1);
-    const bf16* yp = a.dy + ((size_t)n * a.D + odc) * plane * a.Cout;
+      for (int k = 0; k < NPT; ++k) {
+        u32x4 v = rg[k];
+        if (PRO) v = affine_relu8(v, scv, shv);
+        if (!(pin && ok[k])) v = (u32x4){0u, 0u, 0u, 0u};
+        if (k < NPT - 1 || tid + k * 256 < HP * 4) *reinterpret_cast<u32x4*>(smem + slot * PLB + loff[k]) = v;
+      }
+    };
+    auto load_y = [&](int od, u32x4 (&rg)[2]) __attribute__((always_inline)) {
+      const int odc = min(od, a.D - 1);
+      const bf16* yp = a.dy + ((size_t)n * a.D + odc) * plane * a.Cout;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) rg[k] = *reinterpret_cast<const u32x4*>(yp + yoff[k]);
-  };
-  auto store_y_piece = [&](int k, int od, int buf, u32x4 (&rg)[2]) __attribute__((always_inline)) {
-    const bool pin = od < d1;
-    u32x4 v = rg[k];
-    if (!(pin && yok[k])) v = (u32x4){0u, 0u, 0u, 0u};
+      for (int k = 0; k < 2; ++k) rg[k] = *reinterpret_cast<const u32x4*>(yp + yoff[k]);
+    };
+    auto store_y = [&](int od, int buf, u32x4 (&rg)[2]) __attribute__((always_inline)) {
+      const bool pin = od < d1;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        u32x4 v = rg[k];
+        if (!(pin && yok[k])) v = (u32x4){0u, 0u, 0u, 0u};
+        if (do_bias) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { bsum[2 * j] += bf_lo(v[j]); bsum[2 * j + 1] += bf_hi(v[j]); }
+        }
+        *reinterpret_cast<u32x4*>(ys + buf * YPL + yl[k]) = v;
+      }
+    };
+
+    // two register sets: planes (od + 2, od + 1) of iteration `it` were requested during iteration it - 1
+    u32x4 xa[NPT], ya[2], xb[NPT], yb[2];
+    {
+      u32x4 r0[NPT], r1[NPT], r2[NPT], y0[2];
+      load_x(d0 - 1, r0);
+      load_x(d0, r1);
+      load_x(d0 + 1, r2);
+      load_y(d0, y0);
+      load_x(d0 + 2, xa);                       // iteration 0's planes
+      load_y(d0 + 1, ya);
+      store_x(d0 - 1, 0, r0);
+      store_x(d0, 1, r1);
+      store_x(d0 + 1, 2, r2);
+      store_y(d0, 0, y0);
+    }
+    PHASE_MARK(4)
+    __syncthreads();
+    for (int it = 0; it < np; it += 2) {
+      {
+        const int od = d0 + it;
+        load_x(od + 3, xb);                     // for iteration it + 1
+        load_y(od + 2, yb);
+        PHASE_MARK(0)
+        store_x(od + 2, (it + 3) & (R - 1), xa);
+        store_y(od + 1, (it + 1) & 1, ya);
+        PHASE_MARK(2)
+        __syncthreads();
+        PHASE_MARK(3)
+      }
+      if (it + 1 < np) {
+        const int od = d0 + it + 1;
+        load_x(od + 3, xa);
+        load_y(od + 2, ya);
+        PHASE_MARK(0)
+        store_x(od + 2, (it + 4) & (R - 1), xb);
+        store_y(od + 1, (it + 2) & 1, yb);
+        PHASE_MARK(2)
+        __syncthreads();
+        PHASE_MARK(3)
+      }
+    }
     if (do_bias) {
+      // the consumers are done with the LDS planes behind the walk's last barrier: the bias sums go through them
+      float* red = reinterpret_cast<float*>(smem);       // [256][8]
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { bsum[2 * j] += bf_lo(v[j]); bsum[2 * j + 1] += bf_hi(v[j]); }
+      for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
     }
-    *reinterpret_cast<u32x4*>(ys + buf * YPL + yl[k]) = v;
-  };
-  auto store_y = [&](int od, int buf, u32x4 (&rg)[2]) __attribute__((always_inline)) {
+    __syncthreads();                                     // (A) matched by the consumers
+    float* red = reinterpret_cast<float*>(smem);
+    float* red2 = red + 2048;                            // [8][32]
+    if (do_bias) {
+      // channel c = tid % 32 (piece c/8, element c%8) is held by threads k = c/8 (mod 4); 8 groups of 8 threads
+      // each, then the 8 group sums in order
+      const int c = tid & 31, grp = tid >> 5, pc = c >> 3, j = c & 7;
+      float sacc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) store_y_piece(k, od, buf, rg);
-  };
-
-  {
-    u32x4 r0[NPT], r1[NPT], r2[NPT], y0[2];
-    load_x(d0 - 1, r0);
-    load_x(d0, r1);
-    load_x(d0 + 1, r2);
-    load_y(d0, y0);
-    store_x(d0 - 1, 0, r0);
-    store_x(d0, 1, r1);
-    store_x(d0 + 1, 2, r2);
-    store_y(d0, 0, y0);
+      for (int i = 0; i < 8; ++i) sacc += red[(pc + 4 * (grp * 8 + i)) * 8 + j];
+      red2[grp * 32 + c] = sacc;
+    }
+    __syncthreads();                                     // (B)
+    if (do_bias && tid < 32) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sacc += red2[i * 32 + tid];
+      a.bpart[(size_t)blockIdx.x * a.Cout + co0 + tid] = sacc;
+    }
+    PHASE_MARK(6)
+#ifdef DEVIS_PHASE_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+      long long* dbg = reinterpret_cast<long long*>(a.bpart + (size_t)gridDim.x * a.Cout) + (4 + wave) * 8;
+      for (int i = 0; i < 8; ++i) dbg[i] = ph[i];
+    }
+#endif
+    return;
   }
-  __syncthreads();
 
+  // -------------------------------------------------------------------- waves 0-3: fragments + MFMAs
   f32x4 acc[7][2][2];
 #pragma unroll
   for (int t = 0; t < 7; ++t)
@@ -723,15 +583,8 @@ k_wgrad3_slab_march(WgSlabArgs a) {
   const bool last_real = wave + 24 < 27;
 
   PHASE_MARK(4)
-  const int np = d1 - d0;
+  __syncthreads();
   for (int it = 0; it < np; ++it) {
-    const int od = d0 + it;
-    u32x4 prex[NPT], prey[2];
-    load_x(od + 2, prex);
-    load_y(od + 1, prey);
-    __builtin_amdgcn_sched_barrier(0);
-    PHASE_MARK(0)
-
     const char* yb[2];
 #pragma unroll
     for (int mo = 0; mo < 2; ++mo) yb[mo] = ys + (it & 1) * YPL + ya[mo];
@@ -800,17 +653,14 @@ k_wgrad3_slab_march(WgSlabArgs a) {
       SLAB_INTERLEAVE(2)
       __builtin_amdgcn_sched_barrier(0);
     }
-
     PHASE_MARK(1)
-    store_x(od + 2, (it + 3) & (R - 1), prex);
-    store_y(od + 1, (it + 1) & 1, prey);
-    PHASE_MARK(2)
     __syncthreads();
     PHASE_MARK(3)
   }
 
-  // ---- partial results: D layout col = ci = lane&15, rows co = (lane>>4)*4 + j
-  float* part = a.part + (size_t)blockIdx.x * 27 * a.Cout * a.Cin;
+  // ---- partial results in accumulator order: part[gx][slab][tap][mo][mi][lane][4] (lane: ci = lane & 15, the four
+  // values co = (lane >> 4) * 4 + j): one 16-byte store per lane and tile; RED_CONV3F in wgrad_reduce.h reads it back
+  float* part = a.part + ((size_t)blockIdx.x * gridDim.y + slab) * (27 * 4 * 64 * 4);
 #pragma unroll
   for (int tt = 0; tt < 7; ++tt) {
     const int t = wave + 4 * tt;
@@ -818,43 +668,14 @@ k_wgrad3_slab_march(WgSlabArgs a) {
 #pragma unroll
       for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int ci = ci0 + mi * 16 + (lane & 15);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int co = co0 + mo * 16 + g * 4 + j;
-            part[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[tt][mo][mi][j];
-          }
-        }
+        for (int mi = 0; mi < 2; ++mi)
+          *reinterpret_cast<f32x4*>(part + (((t * 2 + mo) * 2 + mi) * 64 + lane) * 4) = acc[tt][mo][mi];
     }
   }
   PHASE_MARK(5)
-  if (do_bias) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);       // [256][8]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
-    __syncthreads();
-    // channel c = tid % 32 (piece c/8, element c%8) is held by threads k = c/8 (mod 4); 8 groups of 8 threads
-    // each, then the 8 group sums in order
-    float* red2 = red + 2048;                          // [8][32]
-    {
-      const int c = tid & 31, grp = tid >> 5, pc = c >> 3, j = c & 7;
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += red[(pc + 4 * (grp * 8 + i)) * 8 + j];
-      red2[grp * 32 + c] = s;
-    }
-    __syncthreads();
-    if (tid < 32) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += red2[i * 32 + tid];
-      a.bpart[(size_t)blockIdx.x * a.Cout + co0 + tid] = s;
-    }
-  }
+  __syncthreads();                                       // (A), (B): the producers' bias reduction
+  __syncthreads();
 #ifdef DEVIS_PHASE_TIMING
-  PHASE_MARK(6)
   if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
     long long* dbg = reinterpret_cast<long long*>(a.bpart + (size_t)gridDim.x * a.Cout) + wave * 8;
     for (int i = 0; i < 8; ++i) dbg[i] = ph[i];
@@ -877,11 +698,6 @@ int wgrad3_slab_march(const devis_conv_desc* d, const void* x, const float* sc, 
   const int64_t cols = (int64_t)a.N * a.nth * a.ntw * nslab;
   int dl = 32;
   while (dl > 4 && cols * cdiv(a.D, dl) < 256) dl >>= 1;
-  {
-    static int dl_env = -1;
-    if (dl_env < 0) { const char* e = getenv("DEVIS_SLAB_DL"); dl_env = e ? atoi(e) : 0; }
-    if (dl_env > 0) dl = dl_env;
-  }
   a.DL = dl;
   a.ndc = (int)cdiv(a.D, dl);
   const int64_t gx = (int64_t)a.N * a.ndc * a.nth * a.ntw;
@@ -894,11 +710,11 @@ int wgrad3_slab_march(const devis_conv_desc* d, const void* x, const float* sc, 
   a.part = (float*)ws; a.bpart = dbias ? (float*)((char*)ws + part_bytes) : nullptr;
   constexpr int LDS = 4 * 10 * 24 * 64 + 2 * 8 * 16 * 64;
   const dim3 grid((unsigned)gx, (unsigned)nslab);
-  if (sc) hipLaunchKernelGGL((k_wgrad3_slab_march<true>), grid, dim3(256), LDS, s, a);
-  else hipLaunchKernelGGL((k_wgrad3_slab_march<false>), grid, dim3(256), LDS, s, a);
+  if (sc) hipLaunchKernelGGL((k_wgrad3_slab_march<true>), grid, dim3(512), LDS, s, a);
+  else hipLaunchKernelGGL((k_wgrad3_slab_march<false>), grid, dim3(512), LDS, s, a);
   int rc = launch_status();
   if (rc) return rc;
-  return launch_wgrad_reduce(a.part, a.bpart, (int)gx, a.Cout, a.Cin, a.Cin, dw, dbias, s);
+  return launch_wgrad_reduce_frag(a.part, a.bpart, (int)gx, a.Cout, a.Cin, dw, dbias, s);
 }
 
 }  // namespace devis

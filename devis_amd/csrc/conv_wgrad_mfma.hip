@@ -221,6 +221,18 @@ int launch_wgrad_reduce(const float* part, const float* bpart, int gx, int Cout,
   return launch_reduce_partials(r, s);
 }
 
+// the same for partials in the accumulator order of k_wgrad3_slab_march (RED_CONV3F in wgrad_reduce.h)
+int launch_wgrad_reduce_frag(const float* part, const float* bpart, int gx, int Cout, int Cin, float* dw, float* dbias,
+                             hipStream_t s) {
+  if (g_wgrad_stage1_only) return DEVIS_OK;
+  RedArgs r;
+  r.part = part; r.bpart = bpart; r.dw = dw; r.dbias = dbias;
+  r.nparts = gx; r.nbparts = gx; r.Cb = Cout;
+  r.pstride = (int64_t)27 * Cout * Cin; r.total = r.pstride;
+  r.mode = RED_CONV3F; r.A = Cout; r.B = Cin; r.cin_real = Cin;
+  return launch_reduce_partials(r, s);
+}
+
 int wgrad3_c16_march(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,
                      float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t s, bool query, size_t* need);
 int wgrad3_slab_march(const devis_conv_desc* d, const void* x, const float* sc, const float* sh, const void* dy,
@@ -272,8 +284,7 @@ static int wgrad_dispatch(const devis_conv_desc* d, const void* x, const float* 
   const int ci = (int)d->C1, co = (int)d->Cout, st = d->SD;
 #define WG(CIS, COS, TD, TH, S, SM) return launch_wgrad<CIS, COS, TD, TH, S, SM>(d, x, sc, sh, dy, dw, dbias, ws, ws_bytes, s, query, need)
   if (st == 1) {
-    static const bool no_march = getenv("DEVIS_NO_MARCH") != nullptr;
-    if (!no_march && co == 16 && (ci == 16 || (ci == 4 && !sc))) {
+    if (co == 16 && (ci == 16 || (ci == 4 && !sc))) {
       const int rc = wgrad3_c16_march(d, x, sc, sh, dy, dw, dbias, ws, ws_bytes, s, query, need);
       if (rc != DEVIS_ERR_UNSUPPORTED && !(query && ci == 4)) return rc;
       if (query && ci == 4) {       // the prologue variant of the 4-channel layer runs on the tile kernel: size for both
@@ -283,7 +294,7 @@ static int wgrad_dispatch(const devis_conv_desc* d, const void* x, const float* 
         return rc == DEVIS_OK ? rc : rc2;
       }
     }
-    if (!no_march && ci % 32 == 0 && co % 32 == 0 && ci <= 128 && co <= 128) {
+    if (ci % 32 == 0 && co % 32 == 0 && ci <= 128 && co <= 128) {
       const int rc = wgrad3_slab_march(d, x, sc, sh, dy, dw, dbias, ws, ws_bytes, s, query, need);
       if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
     }
@@ -291,10 +302,9 @@ static int wgrad_dispatch(const devis_conv_desc* d, const void* x, const float* 
     if (ci == 16 && co == 16) WG(16, 16, 4, 4, 1, false);
     if (ci % 32 == 0 && co % 32 == 0 && ci <= 128 && co <= 128) WG(32, 32, 4, 4, 1, false);
   } else if (st == 2) {
-    // 16 -> 32 without a prologue (EnDown1): plane march (conv_wgrad_s2_march.hip); DEVIS_NO_S2_MARCH=1: the tile kernel.
+    // 16 -> 32 without a prologue (EnDown1): plane march (conv_wgrad_s2_march.hip).
     // A query sizes the workspace for both (the prologue variant stays on the tile kernel).
-    static const bool no_s2_march = getenv("DEVIS_NO_S2_MARCH") != nullptr;
-    if (!no_s2_march && ci == 16 && co == 32 && (query || !sc)) {
+    if (ci == 16 && co == 32 && (query || !sc)) {
       const int rc = wgrad3_s2_c16_march(d, x, dy, dw, dbias, ws, ws_bytes, s, query, need);
       if (!query && rc != DEVIS_ERR_UNSUPPORTED) return rc;
       if (query) {

@@ -779,15 +779,12 @@ static inline unsigned fin_threads(int64_t nout) { return (unsigned)(64 * (nout 
 // The sector-coalesced reduction (reduce_chunks, fast): nout a power of two <= 64, 17x the LDS, 1024 threads.
 struct FinPlan { int fast; unsigned threads; size_t smem; };
 static inline FinPlan fin_plan(int64_t nn, int64_t nout) {
-  static const bool off = getenv("DEVIS_NO_FAST_FINALIZE") != nullptr;
   // block size of the sector-coalesced path: these 8..16-block kernels sit on backward's serial path while the
   // weight-gradient kernels of the side stream hold most of every CU, and a smaller block finds room sooner
-  // (DEVIS_FINALIZE_THREADS = a multiple of 64 up to 1024, for A/B runs)
   // measured in the step, GPU-bound: 1024 threads 4.565 ms, 512: 4.483, 256: 4.508, one wave per output 4.552
-  static const unsigned thr = getenv("DEVIS_FINALIZE_THREADS") ? (unsigned)atoi(getenv("DEVIS_FINALIZE_THREADS")) : 512u;
-  const unsigned t = (thr >= 64u && thr <= 1024u && thr % 64u == 0) ? thr : 512u;
+  const unsigned t = 512u;
   const size_t slow = (size_t)(nn * nout) * sizeof(double), quick = slow * (t / 64 + 1);
-  if (!off && nout >= 1 && nout <= 64 && (nout & (nout - 1)) == 0 && quick <= DEVIS_FINALIZE_SMEM_MAX) return {1, t, quick};
+  if (nout >= 1 && nout <= 64 && (nout & (nout - 1)) == 0 && quick <= DEVIS_FINALIZE_SMEM_MAX) return {1, t, quick};
   return {0, fin_threads(nn * nout), slow};
 }
 

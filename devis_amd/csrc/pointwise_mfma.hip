@@ -376,10 +376,9 @@ int conv2s2_dgrad_mfma(const devis_conv_desc* d, const void* dy, const void* w_d
 // gemm_convt.hip: the wide 2-D layers
 int convT_fwd_gemm(const devis_convT_desc*, const void*, const void*, const float*, void*, hipStream_t);
 int convT_dgrad_gemm(const devis_convT_desc*, const void*, const void*, void*, hipStream_t);
-static bool convt_gemm_on() { static const bool off = getenv("DEVIS_NO_CONVT_GEMM") != nullptr; return !off; }
 
 int convT_fwd_mfma(const devis_convT_desc* d, const void* x, const void* w, const float* bias, void* y, hipStream_t s) {
-  if (convt_gemm_on()) {
+  {
     const int rc = convT_fwd_gemm(d, x, w, bias, y, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
@@ -397,7 +396,7 @@ int convT_fwd_mfma(const devis_convT_desc* d, const void* x, const void* w, cons
 
 // w_t: [Cin][T*Cout] = devis_repack_conv_weight_dgrad(packed convT weight viewed as [T*Cout][1][Cin])
 int convT_dgrad_mfma(const devis_convT_desc* d, const void* dy, const void* w_t, void* dx, hipStream_t s) {
-  if (convt_gemm_on()) {
+  {
     const int rc = convT_dgrad_gemm(d, dy, w_t, dx, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }

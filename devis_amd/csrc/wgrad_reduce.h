@@ -8,7 +8,7 @@
 
 namespace devis {
 
-enum { RED_CONV3 = 0, RED_PW = 1 };
+enum { RED_CONV3 = 0, RED_PW = 1, RED_CONV3F = 2 };
 
 struct RedArgs {
   const float* part;    // [nparts][pstride]
@@ -20,6 +20,8 @@ struct RedArgs {
   int64_t total;        // floats of a partial that are summed (multiple of 4)
   int mode;             // RED_CONV3: o = (t*A + co)*B + ci -> dw[(co*cin_real + ci)*T + t], ci < cin_real, T = total/(A*B)
   int A, B, cin_real;   // RED_PW:    o = p*B + mn          -> dw[mn*A + p]   (A = taps T, B = M*N)
+                        // RED_CONV3F (27 taps, accumulator order of k_wgrad3_slab_march): o = ((((slab*27 + t)*2 + mo)*2 + mi)*64
+                        //   + lane)*4 + j, slab = (co/32)*(B/32) + ci/32 -> co = co0 + mo*16 + (lane>>4)*4 + j, ci = ci0 + mi*16 + lane%16
   // RED_PW with channel slabs (nms > 0): mn = (z*msub + m)*nsub + n, z = ns*nms + ms -> row ms*msub + m, column ns*nsub + n
   int nms = 0, msub = 0, nsub = 0, ntot = 0;
 };
@@ -84,6 +86,11 @@ k_reduce_partials(RedArgs a) {
         const int ci = (int)(o % a.B), co = (int)((o / a.B) % a.A), t = (int)(o / ((int64_t)a.A * a.B));
         const int T = (int)(a.total / ((int64_t)a.A * a.B));          // 27 (3x3x3) or 9 (3x3)
         if (ci < a.cin_real) a.dw[((int64_t)co * a.cin_real + ci) * T + t] = sv[j];
+      } else if (MODE == RED_CONV3F) {
+        const int ln = (int)((o >> 2) & 63), mi = (int)((o >> 8) & 1), mo = (int)((o >> 9) & 1);
+        const int ts = (int)(o >> 10), t = ts % 27, slab = ts / 27, nci = a.B >> 5;
+        const int co = (slab / nci) * 32 + mo * 16 + (ln >> 4) * 4 + j, ci = (slab % nci) * 32 + mi * 16 + (ln & 15);
+        a.dw[((int64_t)co * a.B + ci) * 27 + t] = sv[j];
       } else {
         const int64_t mn = o % a.B;
         const int p = (int)(o / a.B);
@@ -108,6 +115,7 @@ template <int LANES>
 static inline void launch_reduce_lanes(const RedArgs& a, int64_t n4, hipStream_t s) {
   const dim3 grid((unsigned)cdiv(n4, LANES));
   if (a.mode == RED_CONV3) hipLaunchKernelGGL((k_reduce_partials<RED_CONV3, LANES>), grid, dim3(1024), 0, s, a);
+  else if (a.mode == RED_CONV3F) hipLaunchKernelGGL((k_reduce_partials<RED_CONV3F, LANES>), grid, dim3(1024), 0, s, a);
   else hipLaunchKernelGGL((k_reduce_partials<RED_PW, LANES>), grid, dim3(1024), 0, s, a);
 }
 

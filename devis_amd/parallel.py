@@ -36,8 +36,8 @@ class FlatGradSync:
         self.world, self.group = world, group
         self.flat, self.bounds, self.works = None, None, []
         try:
-            # RCCL averages in the collective; gloo cannot.  DEVIS_DP_SUM=1: SUM + one div_ (A/B timing)
-            self._avg = dist.get_backend(group) == "nccl" and os.environ.get("DEVIS_DP_SUM", "0") != "1"
+            # RCCL averages in the collective; gloo cannot (SUM + one div_ there)
+            self._avg = dist.get_backend(group) == "nccl"
         except Exception:
             self._avg = False
 

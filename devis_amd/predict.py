@@ -100,8 +100,30 @@ class GraphedPatchHead:
 _PATCH_STREAMS = {}
 
 
+def hw_queue_limit() -> int:
+    """Hardware queues a process gets on one GPU (HIP's GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise).
+    Streams beyond that share an in-order queue with another stream: work of one then stands behind a WAIT of the
+    other (seen in the data-parallel step, DESIGN.md section 5: RCCL's stream on the main stream's queue), and a
+    rotation whose streams wait on events of each other's queue-mates can stop making progress (the 4-stream run
+    of r02 that did not finish).  Every multi-stream path of the package keeps its streams below this number."""
+    import os
+    try:
+        return max(1, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+    except ValueError:
+        return 4
+
+
+def max_patch_streams() -> int:
+    """Rotation streams sliding_window_infer accepts: one hardware queue stays with the caller's stream."""
+    return max(1, hw_queue_limit() - 1)
+
+
 def _patch_streams(device, n):
     """n cached streams of `device` for the patch rotation."""
+    if n > max_patch_streams():
+        raise ValueError("graph_streams = %d: at most %d rotation streams (the caller's stream and the rotation "
+                         "together must fit the process's %d hardware queues, GPU_MAX_HW_QUEUES)"
+                         % (n, max_patch_streams(), hw_queue_limit()))
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     have = _PATCH_STREAMS.setdefault(key, [])
     while len(have) < n:
@@ -167,9 +189,14 @@ def sliding_window_infer(x, backbone, thresholds=(), rank: int = 0, world: int =
     rounding only - the default stays 1 (the reference's order).
     `graph_streams` = n > 0 keeps the batch-1 launches (bit-identical maps in every dtype) but replays each
     patch from a cached HIP graph (GraphedPatchHead) and rotates the patches over n streams: the host no longer
-    paces the launches and neighbouring patches fill the CUs the 32^3 / 16^3 layers leave idle.
+    paces the launches and neighbouring patches fill the CUs the 32^3 / 16^3 layers leave idle.  n is refused
+    (ValueError) above max_patch_streams() = hardware queues of the process - 1 (3 here; hw_queue_limit()).
     """
     from .parallel import shard_patches
+    if int(graph_streams) > max_patch_streams():
+        raise ValueError("graph_streams = %d: at most %d rotation streams (with the caller's stream they must fit the "
+                         "process's %d hardware queues, GPU_MAX_HW_QUEUES)"
+                         % (graph_streams, max_patch_streams(), hw_queue_limit()))
     run = patch_fn if patch_fn is not None else _default_head(backbone, thresholds, want_evidence, want_mne)
     vol = tuple(x.shape[2:4]) + (155,)
     out = {}

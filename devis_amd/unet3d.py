@@ -27,24 +27,18 @@ G3 = ConvGeom((3, 3, 3), (1, 1, 1), (1, 1, 1))
 G3S2 = ConvGeom((3, 3, 3), (2, 2, 2), (1, 1, 1))
 G1 = ConvGeom((1, 1, 1), (1, 1, 1), (0, 0, 0))
 G2S2 = ConvGeom((2, 2, 2), (2, 2, 2), (0, 0, 0))
-# DEVIS_NO_UPCAT_FUSE=1: run DeUp_Cat's ConvT and 1x1 as two layers (the path every unsupported shape takes)
-import os as _os
-_UPCAT_FUSE = _os.environ.get("DEVIS_NO_UPCAT_FUSE", "0") != "1"
-# DEVIS_NO_UPCAT_BWD_FUSE=1: its two data gradients from the 1x1 dgrad and the k2-s2 gather kernels (A/B timing)
-_UPCAT_BWD_FUSE = _os.environ.get("DEVIS_NO_UPCAT_BWD_FUSE", "0") != "1"
+# Schedule constants of the two-stream backward (measured in the step, DESIGN.md "two-stream backward"; tools/lag_check.py
+# and tools/lag_diff.py set them on the module for A/B runs - no environment switches).
 # weight-gradient calls handed to the side stream per event (see _Run._wg)
-_WG_BATCH = max(1, int(_os.environ.get("DEVIS_WGRAD_BATCH", "2")))
-# DEVIS_WGRAD_LAG = "a:b": a weight-gradient call on tensors of >= _WG_BIG elements (the full-resolution layers) is
-# handed to the side stream `a` schedule blocks after the one that issued it, the others `b` blocks after (_Run._tick)
-_WG_LAG = tuple(int(v) for v in _os.environ.get("DEVIS_WGRAD_LAG", "1:2").split(":"))
+_WG_BATCH = 2
+# (a, b): a weight-gradient call on tensors of >= _WG_BIG elements (the full-resolution layers) is handed to the side
+# stream `a` schedule blocks after the one that issued it, the others `b` blocks after (_Run._tick)
+_WG_LAG = (1, 2)
 _WG_BIG = 1 << 24
-# DEVIS_NO_NBWD_FUSE=1: the norm-backward elementwise pass and the dgrad that consumes it as two kernels everywhere
-# (the 16-channel layers fuse them: ops.conv_dgrad_normbwd)
-_NBWD_FUSE = _os.environ.get("DEVIS_NO_NBWD_FUSE", "0") != "1"
 # The main stream ends its backward before the side stream has worked off its queue (0.3 ms of weight gradients ran
-# alone at the end of the step).  DEVIS_WGRAD_TAIL_MAIN = k: the last k weight-gradient calls of the 3-D U-Net's
-# backward (InitConv; EnBlock1.conv1; EnBlock1.conv2) run on the main stream instead, beside the side stream's queue.
-_WG_TAIL_MAIN = int(_os.environ.get("DEVIS_WGRAD_TAIL_MAIN", "2"))
+# alone at the end of the step): the last _WG_TAIL_MAIN weight-gradient calls of the 3-D U-Net's backward
+# (InitConv; EnBlock1.conv1; EnBlock1.conv2) run on the main stream instead, beside the side stream's queue.
+_WG_TAIL_MAIN = 2
 
 
 # ------------------------------------------------------------ parameter holders
@@ -157,7 +151,7 @@ class _Run:
     def de_up_cat(self, name, x, prev):
         w1 = self._w(name + ".conv1")
         t = ops.conv_fwd(x, None, w1, self.P[name + ".conv1.bias"], G1)
-        if _UPCAT_FUSE and ops.upcat_supported(prev, t):
+        if ops.upcat_supported(prev, t):
             # ConvT + cat + 1x1 in one pass on composite weights (csrc/upcat.hip): `up` is never written
             m = ops.upcat_prepare(self.P[name + ".conv3.weight"], self.P[name + ".conv3.bias"],
                                   self.P[name + ".conv2.weight"], self.P[name + ".conv2.bias"])
@@ -275,9 +269,8 @@ class _Run:
         if partials is None:
             partials = ops._moment_partials(xn, gr, st[0], st[1])
         coef, dgam, dbet = ops.norm_bwd_coeffs(partials, n, v, c, gamma, st[2], st[3], groups, bn, out)
-        fused = None
-        if _NBWD_FUSE:
-            fused = ops.conv_dgrad_normbwd(gr, xn, st[0], st[1], coef, wfwd, self._wd(cname), G3, residual=residual, norm=norm)
+        # None: a layer the fused kernel does not cover (anything but the 16-channel 3x3x3 ones)
+        fused = ops.conv_dgrad_normbwd(gr, xn, st[0], st[1], coef, wfwd, self._wd(cname), G3, residual=residual, norm=norm)
         if fused is not None:
             dx, dh, pt = fused
         else:
@@ -332,11 +325,7 @@ class _Run:
                      P[name + ".conv2.bias"], out=self._o(name + ".conv3") + self._o(name + ".conv2"))
             for k in (".conv3.weight", ".conv3.bias", ".conv2.weight", ".conv2.bias"):
                 g[name + k] = self.G[name + k]
-            if _UPCAT_BWD_FUSE:
-                dprev, dt = ops.upcat_bwd_data(dy, m)
-            else:
-                dprev = ops.conv_dgrad(dy, m["w3a"], G1, prev.shape, wd=m["w3a_t"])[0]
-                dt = ops.conv_fwd(dy, None, m["wq"], None, G2S2)      # d t = sum_p M[p]^T dy[fine(p)]
+            dprev, dt = ops.upcat_bwd_data(dy, m)     # d prev = W3a^T dy; d t = sum_p M[p]^T dy[fine(p)]
         else:
             _, name, x, prev, t, up, w1, wt, w3 = e
             g[name + ".conv3.weight"], g[name + ".conv3.bias"] = self._wg(
@@ -448,8 +437,7 @@ def _side_stream(device):
         # queues (GPU_MAX_HW_QUEUES = 4) round-robin with every other stream; once RCCL has created its streams it
         # landed on the main stream's queue and the two serialised (one-rank RCCL rehearsal: 6.31 ms/step against
         # 5.58 with priority -1; without a process group the two priorities measure the same).
-        prio = int(os.environ.get("DEVIS_WGRAD_STREAM_PRIORITY", "-1"))
-        s = _side_streams[device.index] = torch.cuda.Stream(device, priority=prio)
+        s = _side_streams[device.index] = torch.cuda.Stream(device, priority=-1)
     return s
 
 

@@ -115,3 +115,17 @@ def test_entry_point_refuses_an_unknown_mode_like_the_reference():
     a = getArgs(['--dataset', 'BraTS', '--mode', 'nonsense', '--synthetic', '1'])
     with pytest.raises(NameError):                                   # trainUMIS.py:1447-1449
         run(a)
+
+
+def test_rotation_streams_are_kept_below_the_hardware_queue_count(monkeypatch):
+    """sliding_window_infer refuses more rotation streams than the process has hardware queues to give them
+    (GPU_MAX_HW_QUEUES, 4 by default: the caller's stream + 3); DESIGN.md section 5 says why."""
+    from devis_amd import predict
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert predict.hw_queue_limit() == 4 and predict.max_patch_streams() == 3
+    x = torch.zeros((1, 4, 240, 240, 160))
+    with pytest.raises(ValueError, match="hardware queues"):
+        predict.sliding_window_infer(x, None, patch_fn=lambda p: {}, graph_streams=4)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert predict.max_patch_streams() == 7
+    predict.sliding_window_infer(x, None, patch_fn=lambda p: {}, graph_streams=4)     # patch_fn given: eager loop

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the stride-2 3x3x3 weight gradient 16 -> 32 (EnDown1) at 2 x 128^3 (kernel + partial reduction), HIP events.
-DEVIS_NO_S2_MARCH=1 selects the tile kernel."""
+(A/B against the tile kernel: build the other variant with tools/build_alt.sh and DEVIS_HIP_LIB.)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from devis_amd import ops

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the 3x3x3 weight gradients of the 32 / 64 / 128-channel layers (kernel + partial reduction) at the BraTS step's
-shapes, with and without the norm prologue.  DEVIS_SLAB_DL=n overrides the planes per block."""
+shapes, with and without the norm prologue."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from devis_amd import ops
