@@ -13,6 +13,18 @@ from devis_amd.optim import FusedAdam  # noqa: E402
 from devis_amd.train import adjust_learning_rate, freeze_gc  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+# SCHED="lag=1:2,tail=2,batch=2": the two-stream schedule constants of devis_amd/unet3d.py for this run (A/B sweeps)
+for kv in filter(None, os.environ.get("SCHED", "").split(",")):
+    from devis_amd import unet3d
+    k, v = kv.split("=")
+    if k == "lag":
+        unet3d._WG_LAG = tuple(int(t) for t in v.split(":"))
+    elif k == "tail":
+        unet3d._WG_TAIL_MAIN = int(v)
+    elif k == "batch":
+        unet3d._WG_BATCH = int(v)
+    else:
+        sys.exit("SCHED: unknown key " + k)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 args = bench.brats_args(torch.bfloat16)
