@@ -177,6 +177,25 @@ def test_full_volume_config5_inference_vs_oracle_live():
         d = ((um >> j) & 1).bool() != want
         assert bool(((u[d] - np.float32(t)).abs() < 1e-5).all()), (t, int(d.sum()))
         check(int(d.sum()) / d.numel(), 1e-5, "u > %.2f mask: fraction of voxels that differ (near-ties)" % t)
+    # The shipped bf16 path on the same volume and weights: evidence / u to the bf16 bar, and the mask agreement as a
+    # recorded figure.  A random-init network's class probabilities are close together, so the fraction that differs
+    # here is an upper bound for a trained one; every voxel that differs must be one whose oracle margin is within
+    # twice the largest probability error of the bf16 run (an argmax cannot flip otherwise).
+    from tests.util import BF16_BAR
+    mb = TMSU(brats_args(compute_dtype=torch.bfloat16)).eval()
+    mb.load_state_dict(m.state_dict())
+    outb = T.predict_volume(mb, x.cuda(), 'BraTS', thr)
+    evb = outb["evidence"].cpu()
+    check(rel_err(evb, ev), BF16_BAR, "bf16 evidence, full volume")
+    check((outb["u"].cpu().reshape(u.shape) - u).abs().max(), BF16_BAR, "bf16 u abs, full volume")
+    probb = (evb + 1) / (evb + 1).sum(1, keepdim=True)
+    dp = float((probb - prob.reshape(probb.shape)).abs().max())
+    diffb = outb["pred"].cpu().reshape(pred.shape).long() != pred
+    assert bool((margin[diffb] <= 2 * dp).all()), (dp, float(margin[diffb].max()))
+    check(int(diffb.sum()) / diffb.numel(), 1e-2, "bf16 argmax mask: fraction of voxels that differ from the fp32 oracle (random-init weights)")
+    umb = outb["umask"].cpu().reshape(u.shape).int()
+    worst = max(int((((umb >> j) & 1).bool() != (u > np.float32(t))).sum()) for j, t in enumerate(thr)) / u.numel()
+    check(worst, 1e-2, "bf16 u-threshold masks: largest fraction of voxels that differ (random-init weights)")
 
 
 @pytest.mark.parametrize("model_name,streams", [("U", 1), ("U", 3), ("AU", 3), ("V", 3)])
