@@ -56,6 +56,7 @@ class EvidParams(C.Structure):
 CRIT_DCE, CRIT_DCEU, CRIT_CE, CRIT_MSE, CRIT_KL = range(5)
 PACK_CONV, PACK_CONV_DGRAD, PACK_CONVT, PACK_CONVT_DGRAD = range(4)
 PACK_CHUNK = 1024
+PACK_ROW_FLAG, PACK_ROW_MAX = 0x40000000, 8192
 
 _P, _I64, _I, _F, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _CD, _CTD, _EP = C.POINTER(ConvDesc), C.POINTER(ConvTDesc), C.POINTER(EvidParams)

@@ -199,6 +199,9 @@ class WeightPacker:
         import numpy as np
         self.key = tuple(w.data_ptr() for _, w, _ in entries) + (dtype,)
         want_d = dtype == torch.bfloat16
+        # Row chunks exist from library version 101 on.  An older build given one indexes its item table with the flag
+        # bit set - a GPU memory fault (it happened: a same-box A/B with DEVIS_HIP_LIB pointing at the r02 build).
+        rows_ok = int(_lib.load().devis_version()) >= 101
         plan, off = [], 0
         for name, w, kind in entries:
             if w.dtype != torch.float32 or not w.is_contiguous():
@@ -221,7 +224,12 @@ class WeightPacker:
         self.views = {}
         for i, (name, w, a, b, t, mode, shape, o, n) in enumerate(plan):
             items[i] = (w.data_ptr(), self.arena.data_ptr() + o * es, a, b, t, mode)
-            chunks += [(i, st) for st in range(0, n, _lib.PACK_CHUNK)]
+            # conv modes: one block per output row (coalesced through LDS, csrc/layout.hip) where a row fits
+            row_len = (b if mode == _lib.PACK_CONV else a) * t
+            if rows_ok and mode in (_lib.PACK_CONV, _lib.PACK_CONV_DGRAD) and t > 1 and row_len <= _lib.PACK_ROW_MAX:
+                chunks += [(i | _lib.PACK_ROW_FLAG, r) for r in range(a if mode == _lib.PACK_CONV else b)]
+            else:
+                chunks += [(i, st) for st in range(0, n, _lib.PACK_CHUNK)]
             view = self.arena[o:o + n].view(shape)
             slot = self.views.setdefault(name, [None, None])
             slot[0 if mode in (_lib.PACK_CONV, _lib.PACK_CONVT) else 1] = view

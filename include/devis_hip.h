@@ -75,6 +75,12 @@ int devis_pack_convT_weight(const float* w, void* dst, int64_t Cin, int64_t Cout
  *   DEVIS_PACK_CONVT_DGRAD same src                         -> dst [Cin][taps][Cout]   (w_t of devis_convT_dgrad) */
 enum { DEVIS_PACK_CONV = 0, DEVIS_PACK_CONV_DGRAD = 1, DEVIS_PACK_CONVT = 2, DEVIS_PACK_CONVT_DGRAD = 3 };
 #define DEVIS_PACK_CHUNK 1024
+/* Row chunks of the two conv modes: chunk = (item | DEVIS_PACK_ROW_FLAG, row): the block packs the whole output row
+ * `row` (a cout of DEVIS_PACK_CONV, a cin of DEVIS_PACK_CONV_DGRAD) through LDS with coalesced reads; allowed when a row
+ * (cols * taps, resp. rows * taps elements) has at most DEVIS_PACK_ROW_MAX elements.  Element chunks stay valid for
+ * every mode. */
+#define DEVIS_PACK_ROW_FLAG 0x40000000
+#define DEVIS_PACK_ROW_MAX 8192
 typedef struct devis_pack_item {
   const float* src;
   void* dst;

@@ -525,3 +525,40 @@ def test_conv_dgrad_normbwd_refuses_other_geometries(kernel, pad):
                                       torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert rc == (0 if kernel == (3, 3, 3) else -2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_batch_weight_packing_equals_the_per_tensor_calls(dtype):
+    """devis_pack_weights_batch (one launch per step; row chunks through LDS for the conv modes, element chunks for the
+    rest) against devis_pack_conv_weight / devis_pack_convT_weight / devis_repack_conv_weight_dgrad per tensor, bit for
+    bit: 3-D and 2-D shapes of the nets, the fragment-order layers (64 / 128 channels x 27 taps), 1x1 layers (element
+    chunks), rows at and above DEVIS_PACK_ROW_MAX (1024 x 9 > 8192: element chunks), ragged row lengths."""
+    from devis_amd import _lib, ops
+    g = torch.Generator().manual_seed(3)
+    shapes = (("conv", (16, 4, 3, 3, 3)), ("conv", (32, 16, 3, 3, 3)), ("conv", (64, 64, 3, 3, 3)), ("conv", (128, 128, 3, 3, 3)),
+              ("conv", (4, 16, 1, 1, 1)), ("convT", (64, 32, 2, 2, 2)), ("conv", (32, 64, 1, 1, 1)), ("conv", (32, 3, 3, 3)),
+              ("convT", (256, 128, 2, 2)), ("conv", (512, 512, 3, 3)), ("conv", (64, 1024, 3, 3)), ("conv", (7, 5, 3, 3, 3)),
+              ("conv", (128, 64, 3, 3, 3)), ("conv", (16, 16, 2, 2, 2)))
+    ents = [("w%d" % i, torch.randn(shape, generator=g).cuda(), kind) for i, (kind, shape) in enumerate(shapes)]
+    pk = ops.WeightPacker(ents, dtype, torch.device("cuda"))
+    flags = pk.chunks[:, 0].cpu()
+    assert bool((flags & _lib.PACK_ROW_FLAG).bool().any()) and not bool((flags & _lib.PACK_ROW_FLAG).bool().all())
+    views = pk.pack()
+    lib = _lib.load()
+    for name, w, kind in ents:
+        a, b = w.shape[0], w.shape[1]
+        t = w.numel() // (a * b)
+        fwd, dg = views[name]
+        if kind == "conv":
+            ref = ops.pack_conv_weight(w, dtype)
+            assert torch.equal(fwd.reshape(-1), ref.reshape(-1)), name
+            if dg is not None:
+                refd = torch.empty_like(dg)
+                ops.check(lib.devis_repack_conv_weight_dgrad(ops._p(ref), ops._p(refd), a, b, t, ops.dt_code(dtype), ops._stream()), "repack")
+                assert torch.equal(dg.reshape(-1), refd.reshape(-1)), name + " dgrad"
+        else:
+            ref = ops.pack_convT_weight(w, dtype)
+            assert torch.equal(fwd.reshape(-1), ref.reshape(-1)), name
+            if dg is not None:
+                refd = w.reshape(a, b, t).permute(0, 2, 1).contiguous().to(dtype).reshape(a, t * b)
+                assert torch.equal(dg, refd), name + " dgrad"
