@@ -434,9 +434,15 @@ def main():
     if rank == 0:
         # The roofline line is about the kernel name with the largest summed time in the latest tracked kernel-stats
         # summary of this command (see roofline()); its probes run after the timed region, on the launch stream.
-        out["roofline"], weighted = roofline(a.batch, S, dtype)
-        if weighted is not None:
-            out["roofline_top10_time_weighted"] = weighted
+        if dtype == torch.bfloat16:
+            out["roofline"], weighted = roofline(a.batch, S, dtype)
+            if weighted is not None:
+                out["roofline_top10_time_weighted"] = weighted
+        else:
+            # --dtype fp32 is the parity mode: generic VALU kernels (csrc/conv_direct.hip) with no roofline model;
+            # the tracked kernel-stats summaries and the probes are about the bf16 product path
+            out["roofline"] = None
+            out["note"] = "fp32 parity mode (generic kernels): a secondary number, not the headline configuration"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps, S)
         print(json.dumps(out), flush=True)
