@@ -10,7 +10,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops"
 mkdir -p build
 pids=()
-for f in layout upcat conv_direct conv_mfma conv_march conv_s2_march conv_march32 conv_deepk conv2d_mfma conv_s2_dgrad conv_thin conv_wgrad_mfma conv_wgrad_march conv_wgrad_s2_march pointwise_mfma gemm_convt head1x1 pointwise_wgrad_mfma norm attgate evid evalmaps optim capi; do
+for f in layout upcat conv_direct conv_f32_mfma conv_mfma conv_march conv_s2_march conv_march32 conv_deepk conv2d_mfma conv_s2_dgrad conv_thin conv_wgrad_mfma conv_wgrad_march conv_wgrad_s2_march pointwise_mfma gemm_convt head1x1 pointwise_wgrad_mfma norm attgate evid evalmaps optim capi; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ mfma_common.h -nt build/$f.o ] || [ wgrad_reduce.h -nt build/$f.o ] || [ ../../include/devis_hip.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)

@@ -10,6 +10,13 @@ namespace devis {
 int conv_fwd_direct(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*,
                     const float*, const void*, void*, hipStream_t);
 int conv_dgrad_direct(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, hipStream_t);
+// conv_f32_mfma.hip: fp32 on the matrix cores (any kernel size, stride 1 / 2, channel counts multiples of 16)
+int conv_fwd_f32_mfma(const devis_conv_desc*, const void*, const void*, const void*, const float*, const float*, const float*,
+                      const void*, void*, hipStream_t);
+int conv_dgrad_f32_mfma(const devis_conv_desc*, const void*, const void*, const void*, void*, void*, hipStream_t);
+size_t conv_wgrad_f32_workspace(const devis_conv_desc*);
+int conv_wgrad_f32_mfma(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*, float*, float*,
+                        void*, size_t, hipStream_t);
 int conv_wgrad_direct(const devis_conv_desc*, const void*, const void*, const float*, const float*, const void*,
                       float*, float*, hipStream_t);
 // conv_mfma.hip: return DEVIS_ERR_UNSUPPORTED when the shape is not theirs
@@ -144,6 +151,8 @@ int devis_conv_fwd_stats(const devis_conv_desc* d, const void* x1, const void* x
     rc = first2d_fwd(d, x1, w, bias, residual, y, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
+  rc = conv_fwd_f32_mfma(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);     // the fp32 parity mode
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   return conv_fwd_direct(d, x1, x2, w, bias, in_scale, in_shift, residual, y, s);
 }
 
@@ -175,6 +184,8 @@ int devis_conv_dgrad_stats(const devis_conv_desc* d, const void* dy, const void*
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   rc = conv2s2_dgrad_mfma(d, dy, w_dgrad, residual, dx1, s);
   if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+  rc = conv_dgrad_f32_mfma(d, dy, w_dgrad, residual, dx1, dx2, s);                     // the fp32 parity mode
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   return conv_dgrad_direct(d, dy, w, residual, dx1, dx2, s);
 }
 
@@ -200,8 +211,8 @@ int devis_conv_dgrad(const devis_conv_desc* d, const void* dy, const void* w, co
 
 size_t devis_conv_wgrad_workspace_bytes(const devis_conv_desc* d) {
   if (!conv_desc_ok(d)) return 0;
-  const size_t v[5] = {conv_wgrad_mfma_workspace(d), conv1_wgrad_mfma_workspace(d), conv2s2_wgrad_mfma_workspace(d),
-                       conv2d_wgrad_mfma_workspace(d), first2d_wgrad_workspace(d)};
+  const size_t v[6] = {conv_wgrad_mfma_workspace(d), conv1_wgrad_mfma_workspace(d), conv2s2_wgrad_mfma_workspace(d),
+                       conv2d_wgrad_mfma_workspace(d), first2d_wgrad_workspace(d), conv_wgrad_f32_workspace(d)};
   size_t m = 0;
   for (size_t b : v) m = b > m ? b : m;
   return m;
@@ -226,6 +237,8 @@ int devis_conv_wgrad(const devis_conv_desc* d, const void* x1, const void* x2, c
     rc = first2d_wgrad(d, x1, dy, dw, dbias, ws, ws_bytes, s);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
+  rc = conv_wgrad_f32_mfma(d, x1, x2, in_scale, in_shift, dy, dw, dbias, ws, ws_bytes, s);   // the fp32 parity mode
+  if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   return conv_wgrad_direct(d, x1, x2, in_scale, in_shift, dy, dw, dbias, s);
 }
 

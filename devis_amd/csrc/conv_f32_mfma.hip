@@ -1,0 +1,517 @@
+// fp32 convolution on the matrix cores (v_mfma_f32_16x16x4_f32), channels-last, gfx950: the parity mode
+// (compute_dtype = float32, the reference's own precision) at a usable speed.  The generic direct kernels of
+// conv_direct.hip - one thread per output element, no reuse - ran the BraTS step at 1.9 s; they remain the route for
+// the shapes refused here.
+//
+//   y[v][co] = sum_{tap, ci} W[co][tap][ci] * A[v * S + tap - P][ci] (+ bias, + residual),   A = relu(sc * x + sh)
+//
+// One kernel for every kernel size (taps are a runtime loop), stride 1 or 2 per dimension, one or two input tensors
+// (virtual concat, channel counts multiples of 16; or ONE tensor of 4 channels, zero-extended - the first layer).
+// GEMM orientation as in conv_mfma.hip: M = 16 cout, N = 16 output voxels along W, K = 4 channels per MFMA; the
+// K index of an MFMA is spread over the lane quads so that a lane's four K steps of a 16-channel chunk are 16
+// contiguous bytes: lane (l15, lq) holds channels 4 lq .. 4 lq + 3 of voxel l15 (B, one ds_read_b128) and of weight
+// row l15 (A, one 16-byte global load).  A block stages the halo tile of one 16-channel chunk in LDS (prologue applied,
+// zero padding after it), runs all taps over it, and moves to the next chunk.
+//
+// The same kernel is the data gradient: it runs on the tap-flipped weights [Cin][T'][Cout] with pad K - 1 - P, and for
+// a strided layer over the gradient read as if zero-upsampled by the stride (`U*`: a halo voxel j exists iff every
+// coordinate is a multiple of U, and is voxel j / U of the tensor in memory).  That spends S^3 times the FLOPs of a
+// gather formulation on the three stride-2 layers of the nets - in exchange for no second kernel.
+#include "common.h"
+#include "mfma_common.h"
+#include "wgrad_reduce.h"
+
+namespace devis {
+
+struct F32ConvArgs {
+  const float* x1;
+  const float* x2;     // second input of a virtual concat, or null
+  const float* w;      // [rows >= Cout][T][Cin] fp32
+  const float* bias;   // [Cout] or null
+  const float* sc;     // [N][Cin] or null
+  const float* sh;
+  const float* res;    // like y, or null
+  float* y;
+  int N, MD, MH, MW;   // spatial size of x1 / x2 IN MEMORY
+  int UD, UH, UW;      // virtual upsampling of the input (1 or the stride of the layer whose gradient this is)
+  int OD, OH, OW;      // output
+  int C1, C2, Cout;    // C1 == 4: one 4-channel input, zero-extended to a 16-channel chunk
+  int KD, KH, KW, SD, SH, SW, PD, PH, PW;
+  int HD, HH, HW;      // halo tile
+  int ntd, nth, ntw;
+};
+
+template <int MT, int TD, int TH, bool PRO>
+__global__ void __launch_bounds__(256)
+k_conv_f32_mfma(F32ConvArgs a) {
+  constexpr int TW = 16;
+  constexpr int NT = TD * TH / 4;                 // 16-voxel N tiles per wave
+  static_assert(TD * TH % 4 == 0, "tiles split over four waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  const int tile = blockIdx.x;
+  const int twi = tile % a.ntw;
+  const int thi = (tile / a.ntw) % a.nth;
+  const int tdi = (tile / (a.ntw * a.nth)) % a.ntd;
+  const int n = tile / (a.ntw * a.nth * a.ntd);
+  const int od0 = tdi * TD, oh0 = thi * TH, ow0 = twi * TW;
+  const int co_base = blockIdx.y * (MT * 16);
+  const bool cin4 = a.C1 == 4;
+  const int Cin = cin4 ? 4 : a.C1 + a.C2;         // row length of the weights, channels of sc / sh
+  const int T = a.KD * a.KH * a.KW;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int ubase[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int g = wave * NT + j;
+    const int lth = g % TH, ltd = g / TH;
+    ubase[j] = ((ltd * a.SD) * a.HH + lth * a.SH) * a.HW + l15 * a.SW;
+  }
+  // weight rows of this lane (rows >= Cout do not exist: their fragment is zero)
+  const float* wrow[MT];
+  bool wok[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int co = co_base + m * 16 + l15;
+    wok[m] = co < a.Cout;
+    wrow[m] = a.w + (size_t)(wok[m] ? co : 0) * T * Cin;
+  }
+
+  const int HV = a.HD * a.HH * a.HW;
+  const int nchunks = cin4 ? 1 : (a.C1 + a.C2) / 16;
+  const int jd0 = od0 * a.SD - a.PD, jh0 = oh0 * a.SH - a.PH, jw0 = ow0 * a.SW - a.PW;
+  for (int cc = 0; cc < nchunks; ++cc) {
+    if (cc > 0) __syncthreads();                  // every wave is done with the previous chunk's tile
+    // ---- stage the halo tile of channels [16 cc, 16 cc + 16): 4 pieces of 16 bytes per voxel
+    const int c0 = cc * 16;
+    const bool second = !cin4 && c0 >= a.C1;
+    const float* xb = second ? a.x2 : a.x1;
+    const int cx = second ? a.C2 : a.C1, cofs = second ? c0 - a.C1 : c0;
+    for (int i = tid; i < HV * 4; i += 256) {
+      const int u = i >> 2, piece = i & 3;
+      const int hw = u % a.HW, r = u / a.HW, hh = r % a.HH, hd = r / a.HH;
+      const int jd = jd0 + hd, jh = jh0 + hh, jw = jw0 + hw;
+      bool ok = jd >= 0 && jh >= 0 && jw >= 0 && jd % a.UD == 0 && jh % a.UH == 0 && jw % a.UW == 0;
+      const int id = jd / a.UD, ih = jh / a.UH, iw = jw / a.UW;
+      ok = ok && id < a.MD && ih < a.MH && iw < a.MW && !(cin4 && piece);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const size_t vox = (size_t)((n * a.MD + id) * a.MH + ih) * a.MW + iw;
+        v = *reinterpret_cast<const float4*>(xb + vox * cx + cofs + piece * 4);
+        if (PRO) {
+          const float4 s4 = *reinterpret_cast<const float4*>(a.sc + (size_t)n * Cin + c0 + piece * 4);
+          const float4 h4 = *reinterpret_cast<const float4*>(a.sh + (size_t)n * Cin + c0 + piece * 4);
+          v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+        }
+      }
+      // XOR swizzle of the piece slot: 16 consecutive voxels x one piece land in 16 different 16-byte bank groups
+      *reinterpret_cast<float4*>(smem + u * 64 + ((piece ^ ((u >> 2) & 3)) << 4)) = v;
+    }
+    __syncthreads();
+
+    // ---- all taps over this chunk
+    int t = 0;
+    for (int kd = 0; kd < a.KD; ++kd)
+      for (int kh = 0; kh < a.KH; ++kh)
+        for (int kw = 0; kw < a.KW; ++kw, ++t) {
+          const int toff = (kd * a.HH + kh) * a.HW + kw;
+          f32x4 af[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            af[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (wok[m] && !(cin4 && lq)) af[m] = *reinterpret_cast<const f32x4*>(wrow[m] + (size_t)t * Cin + c0 + lq * 4);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int u = ubase[j] + toff;
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(smem + u * 64 + ((lq ^ ((u >> 2) & 3)) << 4));
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][k], bf[k], acc[m][j], 0, 0, 0);
+          }
+        }
+  }
+
+  // ---- epilogue: a lane holds 4 consecutive cout (4 lq ..) of voxel l15 of each of its tiles
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int g = wave * NT + j;
+    const int lth = g % TH, ltd = g / TH;
+    const int od = od0 + ltd, oh = oh0 + lth, ow = ow0 + l15;
+    if (od >= a.OD || oh >= a.OH || ow >= a.OW) continue;
+    const size_t vox = (size_t)((n * a.OD + od) * a.OH + oh) * a.OW + ow;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int co = co_base + m * 16 + lq * 4;
+      if (co >= a.Cout) continue;                 // Cout is a multiple of 4: a group of four exists or does not
+      float4 o = make_float4(acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]);
+      if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+        o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+      }
+      if (a.res) {
+        const float4 r = *reinterpret_cast<const float4*>(a.res + vox * a.Cout + co);
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      *reinterpret_cast<float4*>(a.y + vox * a.Cout + co) = o;
+    }
+  }
+}
+
+template <int MT, int TD, int TH>
+static int launch_f32(F32ConvArgs& a, hipStream_t s) {
+  a.HD = (TD - 1) * a.SD + a.KD; a.HH = (TH - 1) * a.SH + a.KH; a.HW = 15 * a.SW + a.KW;
+  a.ntd = (int)cdiv(a.OD, TD); a.nth = (int)cdiv(a.OH, TH); a.ntw = (int)cdiv(a.OW, 16);
+  const int64_t tiles = (int64_t)a.N * a.ntd * a.nth * a.ntw;
+  const size_t lds = (size_t)a.HD * a.HH * a.HW * 64;
+  if (tiles > 0x7fffffff || lds > 160 * 1024) return DEVIS_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)tiles, (unsigned)cdiv(a.Cout, MT * 16));
+  if (grid.y > 65535) return DEVIS_ERR_UNSUPPORTED;
+  auto launch = [&](auto k) -> int {
+    if (lds > 65536) {
+      // raised once per kernel and process; the largest tile any caller can ask for is bounded by the check above
+      static thread_local const void* raised[8] = {};
+      bool have = false;
+      for (const void* p : raised) have = have || p == (const void*)k;
+      if (!have) {
+        if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return DEVIS_ERR_HIP;
+        for (const void*& p : raised) if (!p) { p = (const void*)k; break; }
+      }
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    return launch_status();
+  };
+  if (a.sc) return launch(k_conv_f32_mfma<MT, TD, TH, true>);
+  return launch(k_conv_f32_mfma<MT, TD, TH, false>);
+}
+
+static int run_f32(F32ConvArgs& a, hipStream_t s) {
+  // voxel indices are 32-bit in the kernel (element offsets are not)
+  if ((int64_t)a.N * a.MD * a.MH * a.MW >= ((int64_t)1 << 31) || (int64_t)a.N * a.OD * a.OH * a.OW >= ((int64_t)1 << 31))
+    return DEVIS_ERR_UNSUPPORTED;
+  const bool strided = a.SD > 1 || a.SH > 1 || a.SW > 1;
+  if (a.Cout >= 32) return launch_f32<2, 2, 4>(a, s);
+  if (strided) return launch_f32<1, 2, 4>(a, s);       // an 8-row tile of a stride-2 layer does not fit the LDS
+  return launch_f32<1, 2, 8>(a, s);
+}
+
+static bool f32_shape_ok(const devis_conv_desc* d) {
+  if (d->dtype != DEVIS_F32) return false;
+  if (d->SD < 1 || d->SD > 2 || d->SH < 1 || d->SH > 2 || d->SW < 1 || d->SW > 2) return false;
+  if (d->KD > 7 || d->KH > 7 || d->KW > 7) return false;
+  return true;
+}
+
+// forward.  x2 / C2 > 0: virtual concat.
+int conv_fwd_f32_mfma(const devis_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                      const float* sc, const float* sh, const void* res, void* y, hipStream_t s) {
+  if (!f32_shape_ok(d) || d->Cout % 4) return DEVIS_ERR_UNSUPPORTED;
+  const bool first = d->C1 == 4 && d->C2 == 0;
+  if (!first && (d->C1 % 16 || d->C2 % 16)) return DEVIS_ERR_UNSUPPORTED;
+  F32ConvArgs a;
+  a.x1 = (const float*)x1; a.x2 = (const float*)x2; a.w = (const float*)w; a.bias = bias; a.sc = sc; a.sh = sh;
+  a.res = (const float*)res; a.y = (float*)y;
+  a.N = (int)d->N; a.MD = (int)d->ID; a.MH = (int)d->IH; a.MW = (int)d->IW; a.UD = a.UH = a.UW = 1;
+  a.OD = (int)d->OD; a.OH = (int)d->OH; a.OW = (int)d->OW;
+  a.C1 = (int)d->C1; a.C2 = (int)d->C2; a.Cout = (int)d->Cout;
+  a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.SD = d->SD; a.SH = d->SH; a.SW = d->SW; a.PD = d->PD; a.PH = d->PH; a.PW = d->PW;
+  return run_f32(a, s);
+}
+
+// data gradient of the layer `d` describes: w_flip = [C1 + C2][T flipped][Cout] (devis_repack_conv_weight_dgrad).
+// dx1 (and dx2 for a two-input layer) are written by one launch each.
+int conv_dgrad_f32_mfma(const devis_conv_desc* d, const void* dy, const void* w_flip, const void* res, void* dx1, void* dx2,
+                        hipStream_t s) {
+  if (!f32_shape_ok(d) || !w_flip) return DEVIS_ERR_UNSUPPORTED;
+  if ((d->Cout % 16 && d->Cout != 4) || d->C1 % 4 || d->C2 % 4 || (res && d->C2)) return DEVIS_ERR_UNSUPPORTED;
+  if (d->PD > d->KD - 1 || d->PH > d->KH - 1 || d->PW > d->KW - 1) return DEVIS_ERR_UNSUPPORTED;
+  const int T = d->KD * d->KH * d->KW;
+  for (int part = 0; part < (d->C2 ? 2 : 1); ++part) {
+    F32ConvArgs a;
+    a.x1 = (const float*)dy; a.x2 = nullptr; a.bias = nullptr; a.sc = nullptr; a.sh = nullptr;
+    a.w = (const float*)w_flip + (part ? (size_t)d->C1 * T * d->Cout : 0);
+    a.res = part ? nullptr : (const float*)res; a.y = (float*)(part ? dx2 : dx1);
+    a.N = (int)d->N; a.MD = (int)d->OD; a.MH = (int)d->OH; a.MW = (int)d->OW;   // dy in memory
+    a.UD = d->SD; a.UH = d->SH; a.UW = d->SW;
+    a.OD = (int)d->ID; a.OH = (int)d->IH; a.OW = (int)d->IW;
+    a.C1 = (int)d->Cout; a.C2 = 0; a.Cout = (int)(part ? d->C2 : d->C1);
+    a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.SD = a.SH = a.SW = 1;
+    a.PD = d->KD - 1 - d->PD; a.PH = d->KH - 1 - d->PH; a.PW = d->KW - 1 - d->PW;
+    const int rc = run_f32(a, s);
+    if (rc) return rc;
+  }
+  return DEVIS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// fp32 weight gradient on the matrix cores, deterministic (no atomics):
+//
+//   dW[co][tap][ci] = sum_v dy[v][co] * A[v * S + tap - P][ci],   A = relu(sc * x + sh)
+//
+// GEMM: M = 16 cout, N = 16 cin, K = voxels, 4 per MFMA (lane quad lq <-> voxel 4 q + lq of a row of 16).  A block owns
+// NO x NI slabs of 16 x 16 (cout x cin) and marches a (TD x TH x 16)-voxel tile along D; per step it stages the x halo
+// tile (the slab's cin, prologue applied) and the dy tile (the slab's cout) in LDS.  A wave owns ONE slab and keeps the
+// accumulators of all taps (27 x 4 VGPRs); with fewer than four slabs per block the waves of a slab split the K steps
+// and leave a partial each.  One dy fragment feeds every tap: T + 1 LDS reads (ds_read_b32) per T MFMAs.  Partials
+// [part][T][Cout][Cin16] are summed in a fixed order by k_reduce_partials (wgrad_reduce.h), which also scatters into
+// the PyTorch layout; the bias gradient is summed per block from the staged dy tile and reduced by the same launch.
+
+struct F32WgArgs {
+  const float* x1;
+  const float* x2;
+  const float* dy;
+  const float* sc;
+  const float* sh;
+  float* part;
+  float* bpart;        // [spatial blocks][Cout] or null
+  int N, ID, IH, IW, OD, OH, OW;
+  int C1, C2, Cout, cin16;   // cin16: Cin rounded up to 16 (row length of a partial)
+  int SD, SH, SW, PD, PH, PW;
+  int HD, HH, HW;
+  int ntd, nth, ntw, ndc, dsteps;
+  int64_t pstride;
+};
+
+template <int KD, int KH, int KW, int NO, int NI, int TD, int TH, bool PRO>
+__global__ void __launch_bounds__(256)
+k_wgrad_f32_mfma(F32WgArgs a) {
+  constexpr int T = KD * KH * KW;
+  constexpr int NSLAB = NO * NI, NK = 4 / NSLAB;            // waves that share a slab split the K steps
+  constexpr int CI = NI * 16, CO = NO * 16;
+  constexpr int PX = CI == 32 ? 48 : 16, PY = CO == 32 ? 48 : 16;   // pitches (floats): lane quads on distinct banks
+  constexpr int NV = TD * TH * 16, NSTEPS = NV / 4;
+  static_assert(NSLAB == 1 || NSLAB == 2 || NSLAB == 4, "slabs per block");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int slab = wave / NK, kpart = wave % NK;
+  const int mo = slab / NI, mi = slab % NI;
+
+  int sb = blockIdx.x;                                        // spatial block: (n, D chunk, h tile, w tile)
+  const int twi = sb % a.ntw; sb /= a.ntw;
+  const int thi = sb % a.nth; sb /= a.nth;
+  const int dci = sb % a.ndc;
+  const int n = sb / a.ndc;
+  const int co0 = blockIdx.y * CO, ci0 = blockIdx.z * CI;
+  const bool cin4 = a.C1 == 4;
+  const int Cin = cin4 ? 4 : a.C1 + a.C2;
+  const bool second = !cin4 && ci0 >= a.C1;                   // a slab lies in ONE input (C1 is a multiple of CI: host)
+  const float* xb = second ? a.x2 : a.x1;
+  const int cx = second ? a.C2 : a.C1, cofs = second ? ci0 - a.C1 : ci0;
+
+  const int HV = a.HD * a.HH * a.HW;
+  float* xl = reinterpret_cast<float*>(smem);
+  float* yl = xl + (size_t)HV * PX;
+  float* bred = yl + NV * PY;                                 // 256 floats
+
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const int bc = tid % CO, bp = tid / CO;                     // bias: channel and voxel residue of this thread
+  constexpr int BP = 256 / CO;
+
+  const int oh0 = thi * TH, ow0 = twi * 16;
+  const int jh0 = oh0 * a.SH - a.PH, jw0 = ow0 * a.SW - a.PW;
+  const int td_begin = dci * a.dsteps, td_end = min(td_begin + a.dsteps, a.ntd);
+  for (int tdi = td_begin; tdi < td_end; ++tdi) {
+    const int od0 = tdi * TD;
+    const int jd0 = od0 * a.SD - a.PD;
+    if (tdi > td_begin) __syncthreads();                      // the previous tile's fragments are read
+    // ---- x halo tile, CI channels: CI / 4 pieces of 16 bytes per voxel
+    for (int i = tid; i < HV * (CI / 4); i += 256) {
+      const int u = i / (CI / 4), piece = i % (CI / 4);
+      const int hw = u % a.HW, r = u / a.HW, hh = r % a.HH, hd = r / a.HH;
+      const int id = jd0 + hd, ih = jh0 + hh, iw = jw0 + hw;
+      const bool ok = id >= 0 && id < a.ID && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW && !(cin4 && piece);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const size_t vox = (size_t)((n * a.ID + id) * a.IH + ih) * a.IW + iw;
+        v = *reinterpret_cast<const float4*>(xb + vox * cx + cofs + piece * 4);
+        if (PRO) {
+          const float4 s4 = *reinterpret_cast<const float4*>(a.sc + (size_t)n * Cin + ci0 + piece * 4);
+          const float4 h4 = *reinterpret_cast<const float4*>(a.sh + (size_t)n * Cin + ci0 + piece * 4);
+          v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+        }
+      }
+      *reinterpret_cast<float4*>(xl + (size_t)u * PX + piece * 4) = v;
+    }
+    // ---- dy tile, CO channels (channels >= Cout and voxels outside the tensor are zero)
+    for (int i = tid; i < NV * (CO / 4); i += 256) {
+      const int v_ = i / (CO / 4), piece = i % (CO / 4);
+      const int l = v_ & 15, row = v_ >> 4, lth = row % TH, ltd = row / TH;
+      const int od = od0 + ltd, oh = oh0 + lth, ow = ow0 + l;
+      const int co = co0 + piece * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (od < a.OD && oh < a.OH && ow < a.OW && co < a.Cout) {
+        const size_t vox = (size_t)((n * a.OD + od) * a.OH + oh) * a.OW + ow;
+        v = *reinterpret_cast<const float4*>(a.dy + vox * a.Cout + co);
+      }
+      *reinterpret_cast<float4*>(yl + v_ * PY + piece * 4) = v;
+    }
+    __syncthreads();
+    if (a.bpart && blockIdx.z == 0) {
+      for (int v_ = bp; v_ < NV; v_ += BP) bsum += yl[v_ * PY + bc];
+    }
+    // ---- K steps of this wave: 4 voxels each
+    for (int s = kpart; s < NSTEPS; s += NK) {
+      const int row = s >> 2, quad = s & 3, lth = row % TH, ltd = row / TH;
+      const float af = yl[(row * 16 + quad * 4 + lq) * PY + mo * 16 + l15];
+      const float* xp = xl + (size_t)(((ltd * a.SD) * a.HH + lth * a.SH) * a.HW + (quad * 4 + lq) * a.SW) * PX + mi * 16 + l15;
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < KW; ++kw) {
+            const int t = (kd * KH + kh) * KW + kw;
+            const float bf = xp[((kd * a.HH + kh) * a.HW + kw) * PX];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[t], 0, 0, 0);
+          }
+    }
+  }
+
+  // ---- partial of this wave: rows co0 + 16 mo + 4 lq + j, column ci0 + 16 mi + l15 of every tap
+  float* part = a.part + (size_t)((size_t)blockIdx.x * NK + kpart) * a.pstride;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + mo * 16 + lq * 4 + j;
+      if (co < a.Cout) part[((size_t)t * a.Cout + co) * a.cin16 + ci0 + mi * 16 + l15] = acc[t][j];
+    }
+  if (a.bpart && blockIdx.z == 0) {
+    __syncthreads();
+    bred[tid] = bsum;                                         // [bp][bc]
+    __syncthreads();
+    if (tid < CO && co0 + tid < a.Cout) {
+      float s = 0.f;
+      for (int k = 0; k < BP; ++k) s += bred[k * CO + tid];
+      a.bpart[(size_t)blockIdx.x * a.Cout + co0 + tid] = s;
+    }
+  }
+}
+
+struct F32WgPlan {
+  int no, ni, td, th;
+  int ndc, dsteps, nk;
+  int64_t nspatial;
+  size_t lds, part_bytes, total_bytes;
+  F32WgArgs a;
+};
+
+static bool f32_wgrad_plan(const devis_conv_desc* d, F32WgPlan* p) {
+  if (d->dtype != DEVIS_F32) return false;
+  const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3, k133 = d->KD == 1 && d->KH == 3 && d->KW == 3;
+  const bool k111 = d->KD == 1 && d->KH == 1 && d->KW == 1, k222 = d->KD == 2 && d->KH == 2 && d->KW == 2;
+  if (!(k333 || k133 || k111 || k222)) return false;
+  if (d->SD < 1 || d->SD > 2 || d->SH < 1 || d->SH > 2 || d->SW < 1 || d->SW > 2) return false;
+  const bool first = d->C1 == 4 && d->C2 == 0;
+  if (!first && (d->C1 % 16 || d->C2 % 16)) return false;
+  if (d->Cout % 4) return false;
+  if (d->N * d->ID * d->IH * d->IW >= ((int64_t)1 << 31) || d->N * d->OD * d->OH * d->OW >= ((int64_t)1 << 31)) return false;
+  const bool strided = d->SD > 1 || d->SH > 1 || d->SW > 1;
+  const int64_t cin = d->C1 + d->C2;
+  // slabs per block: 2 x 2 where both sides have 32 channels (and a slab pair lies in one input), else fewer
+  if (!strided && d->Cout >= 32 && d->Cout % 32 == 0 && cin >= 32 && d->C1 % 32 == 0 && d->C2 % 32 == 0) { p->no = 2; p->ni = 2; p->td = 2; p->th = 4; }
+  else if (strided && d->Cout >= 32 && d->Cout % 32 == 0) { p->no = 2; p->ni = 1; p->td = 2; p->th = 4; }
+  else if (strided) { p->no = 1; p->ni = 1; p->td = 2; p->th = 4; }
+  else { p->no = 1; p->ni = 1; p->td = 2; p->th = 8; }
+  p->nk = 4 / (p->no * p->ni);
+  F32WgArgs& a = p->a;
+  a.N = (int)d->N; a.ID = (int)d->ID; a.IH = (int)d->IH; a.IW = (int)d->IW; a.OD = (int)d->OD; a.OH = (int)d->OH; a.OW = (int)d->OW;
+  a.C1 = (int)d->C1; a.C2 = (int)d->C2; a.Cout = (int)d->Cout; a.cin16 = first ? 16 : (int)cin;
+  a.SD = d->SD; a.SH = d->SH; a.SW = d->SW; a.PD = d->PD; a.PH = d->PH; a.PW = d->PW;
+  a.HD = (p->td - 1) * d->SD + d->KD; a.HH = (p->th - 1) * d->SH + d->KH; a.HW = 15 * d->SW + d->KW;
+  a.ntd = (int)cdiv(d->OD, p->td); a.nth = (int)cdiv(d->OH, p->th); a.ntw = (int)cdiv(d->OW, 16);
+  const int px = p->ni == 2 ? 48 : 16, py = p->no == 2 ? 48 : 16;
+  p->lds = ((size_t)a.HD * a.HH * a.HW * px + (size_t)p->td * p->th * 16 * py + 256) * sizeof(float);
+  if (p->lds > 160 * 1024) return false;
+  // D tiles per block: as many blocks as it takes to cover the chip about twice, no more (every block leaves partials)
+  const int64_t cols = (int64_t)a.N * a.nth * a.ntw * cdiv(d->Cout, p->no * 16) * cdiv(a.cin16, p->ni * 16);
+  int ndc = (int)cdiv(512, cols);
+  if (ndc < 1) ndc = 1;
+  if (ndc > a.ntd) ndc = a.ntd;
+  a.dsteps = (int)cdiv(a.ntd, ndc);
+  a.ndc = (int)cdiv(a.ntd, a.dsteps);
+  p->ndc = a.ndc; p->dsteps = a.dsteps;
+  p->nspatial = (int64_t)a.N * a.ndc * a.nth * a.ntw;
+  const int T = d->KD * d->KH * d->KW;
+  a.pstride = (int64_t)T * d->Cout * a.cin16;
+  p->part_bytes = (size_t)p->nspatial * p->nk * a.pstride * sizeof(float);
+  p->total_bytes = p->part_bytes + (size_t)p->nspatial * d->Cout * sizeof(float);
+  if (p->nspatial > 0x7fffffff || p->total_bytes > ((size_t)1 << 31)) return false;
+  if (cdiv(d->Cout, p->no * 16) > 65535 || cdiv(a.cin16, p->ni * 16) > 65535) return false;
+  return true;
+}
+
+size_t conv_wgrad_f32_workspace(const devis_conv_desc* d) {
+  F32WgPlan p;
+  return f32_wgrad_plan(d, &p) ? p.total_bytes : 0;
+}
+
+template <int KD, int KH, int KW>
+static int launch_wg_f32(const F32WgPlan& p, hipStream_t s) {
+  const F32WgArgs& a = p.a;
+  const dim3 grid((unsigned)p.nspatial, (unsigned)cdiv(a.Cout, p.no * 16), (unsigned)cdiv(a.cin16, p.ni * 16));
+  const size_t lds = p.lds;
+  auto go = [&](auto k) -> int {
+    if (lds > 65536) {
+      static thread_local const void* raised[32] = {};
+      bool have = false;
+      for (const void* q : raised) have = have || q == (const void*)k;
+      if (!have) {
+        if (check_hip(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return DEVIS_ERR_HIP;
+        for (const void*& q : raised) if (!q) { q = (const void*)k; break; }
+      }
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    return launch_status();
+  };
+#define WGF(NO, NI, TD, TH) \
+  if (p.no == NO && p.ni == NI && p.td == TD && p.th == TH) \
+    return a.sc ? go(k_wgrad_f32_mfma<KD, KH, KW, NO, NI, TD, TH, true>) : go(k_wgrad_f32_mfma<KD, KH, KW, NO, NI, TD, TH, false>)
+  WGF(2, 2, 2, 4);
+  WGF(2, 1, 2, 4);
+  WGF(1, 1, 2, 4);
+  WGF(1, 1, 2, 8);
+#undef WGF
+  return DEVIS_ERR_UNSUPPORTED;
+}
+
+int conv_wgrad_f32_mfma(const devis_conv_desc* d, const void* x1, const void* x2, const float* sc, const float* sh,
+                        const void* dy, float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+  F32WgPlan p;
+  if (!f32_wgrad_plan(d, &p)) return DEVIS_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < p.total_bytes) return DEVIS_ERR_WORKSPACE;
+  F32WgArgs& a = p.a;
+  a.x1 = (const float*)x1; a.x2 = (const float*)x2; a.dy = (const float*)dy; a.sc = sc; a.sh = sh;
+  a.part = (float*)ws; a.bpart = dbias ? (float*)((char*)ws + p.part_bytes) : nullptr;
+  int rc;
+  if (d->KD == 3) rc = launch_wg_f32<3, 3, 3>(p, s);
+  else if (d->KH == 3) rc = launch_wg_f32<1, 3, 3>(p, s);
+  else if (d->KD == 2) rc = launch_wg_f32<2, 2, 2>(p, s);
+  else rc = launch_wg_f32<1, 1, 1>(p, s);
+  if (rc) return rc;
+  RedArgs r;
+  r.part = a.part; r.bpart = a.bpart; r.dw = dw; r.dbias = dbias;
+  r.nparts = (int)(p.nspatial * p.nk); r.nbparts = (int)p.nspatial; r.Cb = a.Cout;
+  r.pstride = a.pstride; r.total = a.pstride;
+  r.mode = RED_CONV3; r.A = a.Cout; r.B = a.cin16; r.cin_real = a.C1 == 4 ? 4 : a.cin16;
+  return launch_reduce_partials(r, s);
+}
+
+}  // namespace devis

@@ -198,7 +198,7 @@ class WeightPacker:
         # entries: [(name, fp32 weight tensor, "conv" | "convT")]
         import numpy as np
         self.key = tuple(w.data_ptr() for _, w, _ in entries) + (dtype,)
-        want_d = dtype == torch.bfloat16
+        want_d = dtype in (torch.bfloat16, torch.float32)      # fp32: the flipped layout of csrc/conv_f32_mfma.hip's dgrad
         # Row chunks exist from library version 101 on.  An older build given one indexes its item table with the flag
         # bit set - a GPU memory fault (it happened: a same-box A/B with DEVIS_HIP_LIB pointing at the r02 build).
         rows_ok = int(_lib.load().devis_version()) >= 101
@@ -212,7 +212,7 @@ class WeightPacker:
             if kind == "conv":          # w [Cout][Cin][T]
                 shapes = [(_lib.PACK_CONV, (a, t, b))] + ([(_lib.PACK_CONV_DGRAD, (b, t, a))] if want_d else [])
             else:                       # w [Cin][Cout][T]
-                shapes = [(_lib.PACK_CONVT, (t, b, a))] + ([(_lib.PACK_CONVT_DGRAD, (a, t * b))] if want_d else [])
+                shapes = [(_lib.PACK_CONVT, (t, b, a))] + ([(_lib.PACK_CONVT_DGRAD, (a, t * b))] if dtype == torch.bfloat16 else [])
             for mode, shape in shapes:
                 plan.append((name, w, a, b, t, mode, shape, off, n))
                 off += (n + 7) // 8 * 8         # 16-byte aligned views
@@ -339,10 +339,12 @@ def conv_dgrad(dy: Tensor, wp: Tensor, geom: ConvGeom, in_shape1, c2: int = 0, r
     dx1 = torch.empty(tuple(in_shape1), dtype=dy.dtype, device=dy.device)
     dx2 = torch.empty(tuple(in_shape1[:-1]) + (c2,), dtype=dy.dtype, device=dy.device) if c2 else None
     lib = _lib.load()
-    if wd is None and dy.dtype == torch.bfloat16 and ((c2 == 0 and geom.k == (3, 3, 3) and geom.s in ((1, 1, 1), (2, 2, 2)))
-                                                      or geom.k == (1, 1, 1)
-                                                      or (c2 == 0 and geom.k == (2, 2, 2) and geom.s == (2, 2, 2))
-                                                      or (geom.k == (1, 3, 3) and geom.s == (1, 1, 1))):
+    # fp32 (the parity mode): csrc/conv_f32_mfma.hip runs every dgrad as a forward conv on the flipped weights
+    if wd is None and (dy.dtype == torch.float32 or dy.dtype == torch.bfloat16 and (
+            (c2 == 0 and geom.k == (3, 3, 3) and geom.s in ((1, 1, 1), (2, 2, 2)))
+            or geom.k == (1, 1, 1)
+            or (c2 == 0 and geom.k == (2, 2, 2) and geom.s == (2, 2, 2))
+            or (geom.k == (1, 3, 3) and geom.s == (1, 1, 1)))):
         # tap-flipped [Cin][T][Cout] packing: dgrad runs on the MFMA forward kernel
         wd = torch.empty((wp.shape[2], wp.shape[1], wp.shape[0]), dtype=wp.dtype, device=wp.device)
         check(lib.devis_repack_conv_weight_dgrad(_p(wp), _p(wd), wp.shape[0], wp.shape[2], wp.shape[1],
