@@ -340,6 +340,14 @@ int conv_wgrad_direct(const devis_conv_desc* d, const void* x1, const void* x2, 
 
 }  // namespace devis
 
+namespace devis {
+// conv_f32_mfma.hip: the fp32 parity mode on the matrix cores
+int convT_fwd_f32_mfma(const devis_convT_desc*, const void*, const void*, const float*, void*, hipStream_t);
+int convT_dgrad_f32_mfma(const devis_convT_desc*, const void*, const void*, void*, hipStream_t);
+size_t convT_wgrad_f32_workspace(const devis_convT_desc*);
+int convT_wgrad_f32_mfma(const devis_convT_desc*, const void*, const void*, float*, void*, size_t, hipStream_t);
+}  // namespace devis
+
 using namespace devis;
 
 extern "C" {
@@ -347,7 +355,9 @@ extern "C" {
 int devis_convT_fwd(const devis_convT_desc* d, const void* x, const void* w, const float* bias, void* y, void* stream) {
   if (!descT_ok(d) || !x || !w || !y) return DEVIS_ERR_BAD_ARG;
   {
-    const int rc = convT_fwd_mfma(d, x, w, bias, y, (hipStream_t)stream);
+    int rc = convT_fwd_mfma(d, x, w, bias, y, (hipStream_t)stream);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+    rc = convT_fwd_f32_mfma(d, x, w, bias, y, (hipStream_t)stream);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
   const ConvTP p = to_tp(d);
@@ -359,7 +369,9 @@ int devis_convT_fwd(const devis_convT_desc* d, const void* x, const void* w, con
 int devis_convT_dgrad(const devis_convT_desc* d, const void* dy, const void* w, const void* w_t, void* dx, void* stream) {
   if (!descT_ok(d) || !dy || !w || !dx) return DEVIS_ERR_BAD_ARG;
   {
-    const int rc = convT_dgrad_mfma(d, dy, w_t, dx, (hipStream_t)stream);
+    int rc = convT_dgrad_mfma(d, dy, w_t, dx, (hipStream_t)stream);
+    if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
+    rc = convT_dgrad_f32_mfma(d, dy, w_t, dx, (hipStream_t)stream);
     if (rc != DEVIS_ERR_UNSUPPORTED) return rc;
   }
   const ConvTP p = to_tp(d);
@@ -368,7 +380,11 @@ int devis_convT_dgrad(const devis_convT_desc* d, const void* dy, const void* w, 
   return launch_status();
 }
 
-size_t devis_convT_wgrad_workspace_bytes(const devis_convT_desc* d) { return descT_ok(d) ? convT_wgrad_mfma_workspace(d) : 0; }
+size_t devis_convT_wgrad_workspace_bytes(const devis_convT_desc* d) {
+  if (!descT_ok(d)) return 0;
+  const size_t a = convT_wgrad_mfma_workspace(d), b = convT_wgrad_f32_workspace(d);
+  return a > b ? a : b;
+}
 
 int devis_convT_wgrad(const devis_convT_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                       void* workspace, size_t workspace_bytes, void* stream) {
@@ -381,11 +397,14 @@ int devis_convT_wgrad(const devis_convT_desc* d, const void* x, const void* dy, 
   hipStream_t s = (hipStream_t)stream;
   const int Tn = p.KD * p.KH * p.KW;
   const int64_t IV = p.N * p.ID * p.IH * p.IW;
-  int rc = check_hip(hipMemsetAsync(dw, 0, sizeof(float) * p.Cin * p.Cout * Tn, s));
-  if (rc) return rc;
-  const dim3 grid((unsigned)cdiv(IV, WG_CHUNK), (unsigned)Tn, (unsigned)(cdiv(p.Cin, 16) * cdiv(p.Cout, 16)));
-  DEVIS_DISPATCH_DTYPE(d->dtype, hipLaunchKernelGGL(k_convT_wgrad<T>, grid, dim3(256), 0, s, p, (const T*)x, (const T*)dy, dw));
-  rc = launch_status();
+  int rc = convT_wgrad_f32_mfma(d, x, dy, dw, workspace, workspace_bytes, s);     // fp32 on the matrix cores (dw only)
+  if (rc == DEVIS_ERR_UNSUPPORTED) {
+    rc = check_hip(hipMemsetAsync(dw, 0, sizeof(float) * p.Cin * p.Cout * Tn, s));
+    if (rc) return rc;
+    const dim3 grid((unsigned)cdiv(IV, WG_CHUNK), (unsigned)Tn, (unsigned)(cdiv(p.Cin, 16) * cdiv(p.Cout, 16)));
+    DEVIS_DISPATCH_DTYPE(d->dtype, hipLaunchKernelGGL(k_convT_wgrad<T>, grid, dim3(256), 0, s, p, (const T*)x, (const T*)dy, dw));
+    rc = launch_status();
+  }
   if (rc || !dbias) return rc;
   rc = check_hip(hipMemsetAsync(dbias, 0, sizeof(float) * p.Cout, s));
   if (rc) return rc;

@@ -13,10 +13,11 @@
 // row l15 (A, one 16-byte global load).  A block stages the halo tile of one 16-channel chunk in LDS (prologue applied,
 // zero padding after it), runs all taps over it, and moves to the next chunk.
 //
-// The same kernel is the data gradient: it runs on the tap-flipped weights [Cin][T'][Cout] with pad K - 1 - P, and for
-// a strided layer over the gradient read as if zero-upsampled by the stride (`U*`: a halo voxel j exists iff every
-// coordinate is a multiple of U, and is voxel j / U of the tensor in memory).  That spends S^3 times the FLOPs of a
-// gather formulation on the three stride-2 layers of the nets - in exchange for no second kernel.
+// The same kernel is the data gradient: it runs on the tap-flipped weights [Cin][T'][Cout] with pad K - 1 - P.  For a
+// strided layer the input voxels fall into S^3 parity classes, each of which sees only the taps of its own parity: one
+// launch per class, a dense stride-1 convolution of the gradient in memory with the class's taps (`T0` / `TS`: first
+// tap and tap step per dimension inside the full kernel) whose outputs are scattered to the class's voxels (`YS*` /
+// `YO*`) - exactly the useful FLOPs, no second kernel.
 #include "common.h"
 #include "mfma_common.h"
 #include "wgrad_reduce.h"
@@ -32,13 +33,17 @@ struct F32ConvArgs {
   const float* sh;
   const float* res;    // like y, or null
   float* y;
-  int N, MD, MH, MW;   // spatial size of x1 / x2 IN MEMORY
-  int UD, UH, UW;      // virtual upsampling of the input (1 or the stride of the layer whose gradient this is)
+  int N, MD, MH, MW;   // spatial size of x1 / x2
   int OD, OH, OW;      // output
   int C1, C2, Cout;    // C1 == 4: one 4-channel input, zero-extended to a 16-channel chunk
-  int KD, KH, KW, SD, SH, SW, PD, PH, PW;
+  int KD, KH, KW, SD, SH, SW, PD, PH, PW;   // K*: taps VISITED per dimension (may be 0: the output is bias + residual)
+  int WT, WKH, WKW;    // the weight rows hold WT taps of a (. , WKH, WKW) kernel, of which tap (T0D + a TSD, ...) is visited
+  int T0D, T0H, T0W, TSD, TSH, TSW;
   int HD, HH, HW;      // halo tile
   int ntd, nth, ntw;
+  // where output voxel (od, oh, ow) lives in y (and res): voxel (od * YSD + YOD, ...) of a (YD, YH, YW) grid.
+  // Identity for a convolution; a transposed convolution with kernel == stride is one 1x1 conv per tap, scattered.
+  int YD, YH, YW, YSD, YSH, YSW, YOD, YOH, YOW;
 };
 
 template <int MT, int TD, int TH, bool PRO>
@@ -60,7 +65,7 @@ k_conv_f32_mfma(F32ConvArgs a) {
   const int co_base = blockIdx.y * (MT * 16);
   const bool cin4 = a.C1 == 4;
   const int Cin = cin4 ? 4 : a.C1 + a.C2;         // row length of the weights, channels of sc / sh
-  const int T = a.KD * a.KH * a.KW;
+  const int T = a.WT;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -99,9 +104,8 @@ k_conv_f32_mfma(F32ConvArgs a) {
       const int u = i >> 2, piece = i & 3;
       const int hw = u % a.HW, r = u / a.HW, hh = r % a.HH, hd = r / a.HH;
       const int jd = jd0 + hd, jh = jh0 + hh, jw = jw0 + hw;
-      bool ok = jd >= 0 && jh >= 0 && jw >= 0 && jd % a.UD == 0 && jh % a.UH == 0 && jw % a.UW == 0;
-      const int id = jd / a.UD, ih = jh / a.UH, iw = jw / a.UW;
-      ok = ok && id < a.MD && ih < a.MH && iw < a.MW && !(cin4 && piece);
+      const int id = jd, ih = jh, iw = jw;
+      const bool ok = id >= 0 && ih >= 0 && iw >= 0 && id < a.MD && ih < a.MH && iw < a.MW && !(cin4 && piece);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) {
         const size_t vox = (size_t)((n * a.MD + id) * a.MH + ih) * a.MW + iw;
@@ -119,11 +123,11 @@ k_conv_f32_mfma(F32ConvArgs a) {
     __syncthreads();
 
     // ---- all taps over this chunk
-    int t = 0;
     for (int kd = 0; kd < a.KD; ++kd)
       for (int kh = 0; kh < a.KH; ++kh)
-        for (int kw = 0; kw < a.KW; ++kw, ++t) {
+        for (int kw = 0; kw < a.KW; ++kw) {
           const int toff = (kd * a.HH + kh) * a.HW + kw;
+          const int t = ((a.T0D + kd * a.TSD) * a.WKH + a.T0H + kh * a.TSH) * a.WKW + a.T0W + kw * a.TSW;
           f32x4 af[MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
@@ -150,7 +154,7 @@ k_conv_f32_mfma(F32ConvArgs a) {
     const int lth = g % TH, ltd = g / TH;
     const int od = od0 + ltd, oh = oh0 + lth, ow = ow0 + l15;
     if (od >= a.OD || oh >= a.OH || ow >= a.OW) continue;
-    const size_t vox = (size_t)((n * a.OD + od) * a.OH + oh) * a.OW + ow;
+    const size_t vox = (size_t)((n * a.YD + od * a.YSD + a.YOD) * a.YH + oh * a.YSH + a.YOH) * a.YW + ow * a.YSW + a.YOW;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int co = co_base + m * 16 + lq * 4;
@@ -196,9 +200,19 @@ static int launch_f32(F32ConvArgs& a, hipStream_t s) {
   return launch(k_conv_f32_mfma<MT, TD, TH, false>);
 }
 
+// every tap of the kernel, outputs where a convolution puts them
+static void dense_output(F32ConvArgs& a) {
+  a.YD = a.OD; a.YH = a.OH; a.YW = a.OW; a.YSD = a.YSH = a.YSW = 1; a.YOD = a.YOH = a.YOW = 0;
+}
+static void all_taps(F32ConvArgs& a) {
+  a.WT = a.KD * a.KH * a.KW; a.WKH = a.KH; a.WKW = a.KW;
+  a.T0D = a.T0H = a.T0W = 0; a.TSD = a.TSH = a.TSW = 1;
+}
+
 static int run_f32(F32ConvArgs& a, hipStream_t s) {
   // voxel indices are 32-bit in the kernel (element offsets are not)
-  if ((int64_t)a.N * a.MD * a.MH * a.MW >= ((int64_t)1 << 31) || (int64_t)a.N * a.OD * a.OH * a.OW >= ((int64_t)1 << 31))
+  if ((int64_t)a.N * a.MD * a.MH * a.MW >= ((int64_t)1 << 31) || (int64_t)a.N * a.OD * a.OH * a.OW >= ((int64_t)1 << 31) ||
+      (int64_t)a.N * a.YD * a.YH * a.YW >= ((int64_t)1 << 31))
     return DEVIS_ERR_UNSUPPORTED;
   const bool strided = a.SD > 1 || a.SH > 1 || a.SW > 1;
   if (a.Cout >= 32) return launch_f32<2, 2, 4>(a, s);
@@ -222,10 +236,12 @@ int conv_fwd_f32_mfma(const devis_conv_desc* d, const void* x1, const void* x2, 
   F32ConvArgs a;
   a.x1 = (const float*)x1; a.x2 = (const float*)x2; a.w = (const float*)w; a.bias = bias; a.sc = sc; a.sh = sh;
   a.res = (const float*)res; a.y = (float*)y;
-  a.N = (int)d->N; a.MD = (int)d->ID; a.MH = (int)d->IH; a.MW = (int)d->IW; a.UD = a.UH = a.UW = 1;
+  a.N = (int)d->N; a.MD = (int)d->ID; a.MH = (int)d->IH; a.MW = (int)d->IW;
   a.OD = (int)d->OD; a.OH = (int)d->OH; a.OW = (int)d->OW;
   a.C1 = (int)d->C1; a.C2 = (int)d->C2; a.Cout = (int)d->Cout;
   a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.SD = d->SD; a.SH = d->SH; a.SW = d->SW; a.PD = d->PD; a.PH = d->PH; a.PW = d->PW;
+  dense_output(a);
+  all_taps(a);
   return run_f32(a, s);
 }
 
@@ -237,23 +253,81 @@ int conv_dgrad_f32_mfma(const devis_conv_desc* d, const void* dy, const void* w_
   if ((d->Cout % 16 && d->Cout != 4) || d->C1 % 4 || d->C2 % 4 || (res && d->C2)) return DEVIS_ERR_UNSUPPORTED;
   if (d->PD > d->KD - 1 || d->PH > d->KH - 1 || d->PW > d->KW - 1) return DEVIS_ERR_UNSUPPORTED;
   const int T = d->KD * d->KH * d->KW;
-  for (int part = 0; part < (d->C2 ? 2 : 1); ++part) {
-    F32ConvArgs a;
-    a.x1 = (const float*)dy; a.x2 = nullptr; a.bias = nullptr; a.sc = nullptr; a.sh = nullptr;
-    a.w = (const float*)w_flip + (part ? (size_t)d->C1 * T * d->Cout : 0);
-    a.res = part ? nullptr : (const float*)res; a.y = (float*)(part ? dx2 : dx1);
-    a.N = (int)d->N; a.MD = (int)d->OD; a.MH = (int)d->OH; a.MW = (int)d->OW;   // dy in memory
-    a.UD = d->SD; a.UH = d->SH; a.UW = d->SW;
-    a.OD = (int)d->ID; a.OH = (int)d->IH; a.OW = (int)d->IW;
-    a.C1 = (int)d->Cout; a.C2 = 0; a.Cout = (int)(part ? d->C2 : d->C1);
-    a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.SD = a.SH = a.SW = 1;
-    a.PD = d->KD - 1 - d->PD; a.PH = d->KH - 1 - d->PH; a.PW = d->KW - 1 - d->PW;
-    const int rc = run_f32(a, s);
-    if (rc) return rc;
-  }
+  const int K[3] = {d->KD, d->KH, d->KW}, S[3] = {d->SD, d->SH, d->SW}, I[3] = {(int)d->ID, (int)d->IH, (int)d->IW};
+  const int Pf[3] = {d->KD - 1 - d->PD, d->KH - 1 - d->PH, d->KW - 1 - d->PW};       // pad of the flipped convolution
+  for (int part = 0; part < (d->C2 ? 2 : 1); ++part)
+    for (int cls = 0; cls < S[0] * S[1] * S[2]; ++cls) {
+      // input voxels i = S k + p of this class, per dimension: dx[i] = sum_{t' = t0 + S a} dy[k + off + a] Wf[t'],
+      // t0 = (p + P') mod S, off = (p - P' + t0) / S (exact), a = 0 .. ceil((K - t0) / S) - 1
+      const int p[3] = {cls / (S[1] * S[2]), (cls / S[2]) % S[1], cls % S[2]};
+      int t0[3], na[3], off[3], cnt[3];
+      bool empty = false;
+      for (int k = 0; k < 3; ++k) {
+        t0[k] = (p[k] + Pf[k]) % S[k];
+        na[k] = t0[k] < K[k] ? (K[k] - t0[k] + S[k] - 1) / S[k] : 0;
+        off[k] = (p[k] - Pf[k] + t0[k]) / S[k];            // the numerator is a multiple of S, of either sign
+        cnt[k] = I[k] > p[k] ? (I[k] - p[k] + S[k] - 1) / S[k] : 0;
+        empty = empty || cnt[k] == 0;
+      }
+      if (empty) continue;
+      F32ConvArgs a;
+      a.x1 = (const float*)dy; a.x2 = nullptr; a.bias = nullptr; a.sc = nullptr; a.sh = nullptr;
+      a.w = (const float*)w_flip + (part ? (size_t)d->C1 * T * d->Cout : 0);
+      a.res = part ? nullptr : (const float*)res; a.y = (float*)(part ? dx2 : dx1);
+      a.N = (int)d->N; a.MD = (int)d->OD; a.MH = (int)d->OH; a.MW = (int)d->OW;
+      a.OD = cnt[0]; a.OH = cnt[1]; a.OW = cnt[2];
+      a.C1 = (int)d->Cout; a.C2 = 0; a.Cout = (int)(part ? d->C2 : d->C1);
+      a.KD = na[0]; a.KH = na[1]; a.KW = na[2]; a.SD = a.SH = a.SW = 1;
+      a.PD = -off[0]; a.PH = -off[1]; a.PW = -off[2];
+      a.WT = T; a.WKH = d->KH; a.WKW = d->KW;
+      a.T0D = t0[0]; a.T0H = t0[1]; a.T0W = t0[2]; a.TSD = S[0]; a.TSH = S[1]; a.TSW = S[2];
+      a.YD = I[0]; a.YH = I[1]; a.YW = I[2]; a.YSD = S[0]; a.YSH = S[1]; a.YSW = S[2]; a.YOD = p[0]; a.YOH = p[1]; a.YOW = p[2];
+      const int rc = run_f32(a, s);
+      if (rc) return rc;
+    }
   return DEVIS_OK;
 }
 
+// ---- transposed convolution with kernel == stride (each K 1 or 2), fp32
+// forward: y[K i + t][co] = sum_ci W[t][co][ci] x[i][ci] + b: one 1x1 conv per tap on the packed weight's slice
+// [Cout][Cin] of tap t, its output scattered to the fine voxels of that tap.
+int convT_fwd_f32_mfma(const devis_convT_desc* d, const void* x, const void* w, const float* bias, void* y, hipStream_t s) {
+  if (d->dtype != DEVIS_F32 || d->Cin % 16 || d->Cout % 4) return DEVIS_ERR_UNSUPPORTED;
+  for (int kd = 0; kd < d->KD; ++kd)
+    for (int kh = 0; kh < d->KH; ++kh)
+      for (int kw = 0; kw < d->KW; ++kw) {
+        const int t = (kd * d->KH + kh) * d->KW + kw;
+        F32ConvArgs a;
+        a.x1 = (const float*)x; a.x2 = nullptr; a.w = (const float*)w + (size_t)t * d->Cout * d->Cin; a.bias = bias;
+        a.sc = nullptr; a.sh = nullptr; a.res = nullptr; a.y = (float*)y;
+        a.N = (int)d->N; a.MD = (int)d->ID; a.MH = (int)d->IH; a.MW = (int)d->IW;
+        a.OD = (int)d->ID; a.OH = (int)d->IH; a.OW = (int)d->IW;
+        a.C1 = (int)d->Cin; a.C2 = 0; a.Cout = (int)d->Cout;
+        a.KD = a.KH = a.KW = 1; a.SD = a.SH = a.SW = 1; a.PD = a.PH = a.PW = 0;
+        all_taps(a);
+        a.YD = (int)d->ID * d->KD; a.YH = (int)d->IH * d->KH; a.YW = (int)d->IW * d->KW;
+        a.YSD = d->KD; a.YSH = d->KH; a.YSW = d->KW; a.YOD = kd; a.YOH = kh; a.YOW = kw;
+        const int rc = run_f32(a, s);
+        if (rc) return rc;
+      }
+  return DEVIS_OK;
+}
+
+// data gradient: dx[i][ci] = sum_{t, co} dy[K i + t][co] W[ci][co][t] - a convolution of dy with kernel = stride = K,
+// no padding, on w_t = [Cin][T][Cout] (devis_repack_conv_weight_dgrad of the packed weight viewed as [T Cout][1][Cin])
+int convT_dgrad_f32_mfma(const devis_convT_desc* d, const void* dy, const void* w_t, void* dx, hipStream_t s) {
+  if (d->dtype != DEVIS_F32 || !w_t || d->Cout % 16 || d->Cin % 4) return DEVIS_ERR_UNSUPPORTED;
+  F32ConvArgs a;
+  a.x1 = (const float*)dy; a.x2 = nullptr; a.w = (const float*)w_t; a.bias = nullptr; a.sc = nullptr; a.sh = nullptr;
+  a.res = nullptr; a.y = (float*)dx;
+  a.N = (int)d->N; a.MD = (int)d->ID * d->KD; a.MH = (int)d->IH * d->KH; a.MW = (int)d->IW * d->KW;
+  a.OD = (int)d->ID; a.OH = (int)d->IH; a.OW = (int)d->IW;
+  a.C1 = (int)d->Cout; a.C2 = 0; a.Cout = (int)d->Cin;
+  a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.SD = d->KD; a.SH = d->KH; a.SW = d->KW; a.PD = a.PH = a.PW = 0;
+  dense_output(a);
+  all_taps(a);
+  return run_f32(a, s);
+}
 
 // ------------------------------------------------------------------------------------------------
 // fp32 weight gradient on the matrix cores, deterministic (no atomics):
@@ -417,7 +491,8 @@ static bool f32_wgrad_plan(const devis_conv_desc* d, F32WgPlan* p) {
   if (d->dtype != DEVIS_F32) return false;
   const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3, k133 = d->KD == 1 && d->KH == 3 && d->KW == 3;
   const bool k111 = d->KD == 1 && d->KH == 1 && d->KW == 1, k222 = d->KD == 2 && d->KH == 2 && d->KW == 2;
-  if (!(k333 || k133 || k111 || k222)) return false;
+  const bool k122 = d->KD == 1 && d->KH == 2 && d->KW == 2;
+  if (!(k333 || k133 || k111 || k222 || k122)) return false;
   if (d->SD < 1 || d->SD > 2 || d->SH < 1 || d->SH > 2 || d->SW < 1 || d->SW > 2) return false;
   const bool first = d->C1 == 4 && d->C2 == 0;
   if (!first && (d->C1 % 16 || d->C2 % 16)) return false;
@@ -504,6 +579,7 @@ int conv_wgrad_f32_mfma(const devis_conv_desc* d, const void* x1, const void* x2
   if (d->KD == 3) rc = launch_wg_f32<3, 3, 3>(p, s);
   else if (d->KH == 3) rc = launch_wg_f32<1, 3, 3>(p, s);
   else if (d->KD == 2) rc = launch_wg_f32<2, 2, 2>(p, s);
+  else if (d->KH == 2) rc = launch_wg_f32<1, 2, 2>(p, s);
   else rc = launch_wg_f32<1, 1, 1>(p, s);
   if (rc) return rc;
   RedArgs r;
@@ -512,6 +588,30 @@ int conv_wgrad_f32_mfma(const devis_conv_desc* d, const void* x1, const void* x2
   r.pstride = a.pstride; r.total = a.pstride;
   r.mode = RED_CONV3; r.A = a.Cout; r.B = a.cin16; r.cin_real = a.C1 == 4 ? 4 : a.cin16;
   return launch_reduce_partials(r, s);
+}
+
+// Weight gradient of the transposed convolution (kernel == stride): dW[ci][co][t] = sum_i x[i][ci] dy[K i + t][co] is
+// the weight gradient of the convolution dy -> x with kernel = stride = K (its "input" is dy, its "output gradient" x),
+// and the reduction's [cout'][cin'][T] order is PyTorch's [Cin][Cout][T].  The bias gradient (a column sum of dy) is
+// left to the caller.
+static bool convT_as_conv(const devis_convT_desc* d, devis_conv_desc* c) {
+  if (d->dtype != DEVIS_F32 || d->Cout % 16 || d->Cin % 4) return false;
+  c->N = d->N; c->ID = d->ID * d->KD; c->IH = d->IH * d->KH; c->IW = d->IW * d->KW;
+  c->OD = d->ID; c->OH = d->IH; c->OW = d->IW;
+  c->C1 = d->Cout; c->C2 = 0; c->Cout = d->Cin;
+  c->KD = d->KD; c->KH = d->KH; c->KW = d->KW; c->SD = d->KD; c->SH = d->KH; c->SW = d->KW; c->PD = c->PH = c->PW = 0;
+  c->dtype = d->dtype;
+  return true;
+}
+size_t convT_wgrad_f32_workspace(const devis_convT_desc* d) {
+  devis_conv_desc c;
+  return convT_as_conv(d, &c) ? conv_wgrad_f32_workspace(&c) : 0;
+}
+int convT_wgrad_f32_mfma(const devis_convT_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+  devis_conv_desc c;
+  if (!convT_as_conv(d, &c)) return DEVIS_ERR_UNSUPPORTED;
+  return conv_wgrad_f32_mfma(&c, dy, nullptr, nullptr, nullptr, x, dw, nullptr, ws, ws_bytes, s);
 }
 
 }  // namespace devis

@@ -212,7 +212,7 @@ class WeightPacker:
             if kind == "conv":          # w [Cout][Cin][T]
                 shapes = [(_lib.PACK_CONV, (a, t, b))] + ([(_lib.PACK_CONV_DGRAD, (b, t, a))] if want_d else [])
             else:                       # w [Cin][Cout][T]
-                shapes = [(_lib.PACK_CONVT, (t, b, a))] + ([(_lib.PACK_CONVT_DGRAD, (a, t * b))] if dtype == torch.bfloat16 else [])
+                shapes = [(_lib.PACK_CONVT, (t, b, a))] + ([(_lib.PACK_CONVT_DGRAD, (a, t * b))] if want_d else [])
             for mode, shape in shapes:
                 plan.append((name, w, a, b, t, mode, shape, off, n))
                 off += (n + 7) // 8 * 8         # 16-byte aligned views
@@ -450,7 +450,7 @@ def convT_dgrad(dy: Tensor, wp: Tensor, k, x_shape, wt: Optional[Tensor] = None)
     d = _tdesc(x_shape, wp.shape[2], wp.shape[1], k, dy.dtype)
     dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
-    if wt is None and dy.dtype == torch.bfloat16:
+    if wt is None and dy.dtype in (torch.bfloat16, torch.float32):
         t, co, ci = wp.shape
         wt = torch.empty((ci, t * co), dtype=wp.dtype, device=wp.device)
         check(lib.devis_repack_conv_weight_dgrad(_p(wp), _p(wt), t * co, ci, 1, dt_code(wp.dtype), _stream()),
