@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -341,6 +342,38 @@ def cpu_baseline(steps, size):
                       "%.2f s/step" % (steps, size, dt)}
 
 
+def fp32_step_ms(batch, size, x, y, steps=3, warmup=2):
+    """ms per training step of the same model in the fp32 parity mode (same inputs, fresh replica)."""
+    from devis_amd import TMSU
+    from devis_amd.optim import FusedAdam
+    from devis_amd.train import adjust_learning_rate
+    args = brats_args(torch.float32)
+    torch.manual_seed(0)
+    model = TMSU(args)
+    model.train()
+    opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=1e-5, module=model)
+
+    def step():
+        adjust_learning_rate(opt, 25, args.end_epochs, args.lr)
+        _, loss = model(x, y, 25, 'train', 'BraTS')
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if not math.isfinite(float(loss.item())):
+        return None
+    return dt / steps * 1e3
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -443,6 +476,10 @@ def main():
             # the tracked kernel-stats summaries and the probes are about the bf16 product path
             out["roofline"] = None
             out["note"] = "fp32 parity mode (generic kernels): a secondary number, not the headline configuration"
+        if world == 1 and dtype == torch.bfloat16 and not a.no_cpu_baseline:
+            # secondary number: the same step at the reference's own precision (compute_dtype = float32: every conv on
+            # v_mfma_f32_16x16x4_f32, csrc/conv_f32_mfma.hip; deterministic weight gradients) - not the headline
+            out["fp32_parity_mode_ms_per_step"] = fp32_step_ms(a.batch, S, x, y)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps, S)
         print(json.dumps(out), flush=True)

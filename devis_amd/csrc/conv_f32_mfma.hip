@@ -100,25 +100,38 @@ k_conv_f32_mfma(F32ConvArgs a) {
     const bool second = !cin4 && c0 >= a.C1;
     const float* xb = second ? a.x2 : a.x1;
     const int cx = second ? a.C2 : a.C1, cofs = second ? c0 - a.C1 : c0;
-    for (int i = tid; i < HV * 4; i += 256) {
-      const int u = i >> 2, piece = i & 3;
-      const int hw = u % a.HW, r = u / a.HW, hh = r % a.HH, hd = r / a.HH;
-      const int jd = jd0 + hd, jh = jh0 + hh, jw = jw0 + hw;
-      const int id = jd, ih = jh, iw = jw;
-      const bool ok = id >= 0 && ih >= 0 && iw >= 0 && id < a.MD && ih < a.MH && iw < a.MW && !(cin4 && piece);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        const size_t vox = (size_t)((n * a.MD + id) * a.MH + ih) * a.MW + iw;
-        v = *reinterpret_cast<const float4*>(xb + vox * cx + cofs + piece * 4);
-        if (PRO) {
-          const float4 s4 = *reinterpret_cast<const float4*>(a.sc + (size_t)n * Cin + c0 + piece * 4);
-          const float4 h4 = *reinterpret_cast<const float4*>(a.sh + (size_t)n * Cin + c0 + piece * 4);
-          v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
-          v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
-        }
+    // four slots per trip, their loads issued together (a slot outside the tensor loads element 0 and is zeroed by a
+    // select: no memory instruction under a divergent branch, and one HBM round trip per trip instead of four)
+    const int piece = tid & 3;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = s4;
+    if (PRO) {
+      s4 = *reinterpret_cast<const float4*>(a.sc + (size_t)n * Cin + c0 + piece * 4);
+      h4 = *reinterpret_cast<const float4*>(a.sh + (size_t)n * Cin + c0 + piece * 4);
+    }
+    for (int i0 = tid; i0 < HV * 4; i0 += 1024) {
+      float4 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int u = (i0 + k * 256) >> 2;
+        const int hw = u % a.HW, r = u / a.HW, hh = r % a.HH, hd = r / a.HH;
+        const int id = jd0 + hd, ih = jh0 + hh, iw = jw0 + hw;
+        ok[k] = u < HV && id >= 0 && ih >= 0 && iw >= 0 && id < a.MD && ih < a.MH && iw < a.MW && !(cin4 && piece);
+        const size_t vox = ok[k] ? (size_t)((n * a.MD + id) * a.MH + ih) * a.MW + iw : 0;
+        v[k] = *reinterpret_cast<const float4*>(xb + (ok[k] ? vox * cx + cofs + piece * 4 : 0));
       }
-      // XOR swizzle of the piece slot: 16 consecutive voxels x one piece land in 16 different 16-byte bank groups
-      *reinterpret_cast<float4*>(smem + u * 64 + ((piece ^ ((u >> 2) & 3)) << 4)) = v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int u = (i0 + k * 256) >> 2;
+        float4 o = v[k];
+        if (PRO) {
+          o.x = fmaxf(fmaf(o.x, s4.x, h4.x), 0.f); o.y = fmaxf(fmaf(o.y, s4.y, h4.y), 0.f);
+          o.z = fmaxf(fmaf(o.z, s4.z, h4.z), 0.f); o.w = fmaxf(fmaf(o.w, s4.w, h4.w), 0.f);
+        }
+        if (!ok[k]) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        // XOR swizzle of the piece slot: 16 consecutive voxels x one piece land in 16 different 16-byte bank groups
+        if (u < HV) *reinterpret_cast<float4*>(smem + u * 64 + ((piece ^ ((u >> 2) & 3)) << 4)) = o;
+      }
     }
     __syncthreads();
 
@@ -399,42 +412,68 @@ k_wgrad_f32_mfma(F32WgArgs a) {
 
   const int oh0 = thi * TH, ow0 = twi * 16;
   const int jh0 = oh0 * a.SH - a.PH, jw0 = ow0 * a.SW - a.PW;
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = s4;    // prologue coefficients of this thread's piece
+  if (PRO) {
+    s4 = *reinterpret_cast<const float4*>(a.sc + (size_t)n * Cin + ci0 + (tid % (CI / 4)) * 4);
+    h4 = *reinterpret_cast<const float4*>(a.sh + (size_t)n * Cin + ci0 + (tid % (CI / 4)) * 4);
+  }
   const int td_begin = dci * a.dsteps, td_end = min(td_begin + a.dsteps, a.ntd);
   for (int tdi = td_begin; tdi < td_end; ++tdi) {
     const int od0 = tdi * TD;
     const int jd0 = od0 * a.SD - a.PD;
     if (tdi > td_begin) __syncthreads();                      // the previous tile's fragments are read
     // ---- x halo tile, CI channels: CI / 4 pieces of 16 bytes per voxel
-    for (int i = tid; i < HV * (CI / 4); i += 256) {
-      const int u = i / (CI / 4), piece = i % (CI / 4);
-      const int hw = u % a.HW, r = u / a.HW, hh = r % a.HH, hd = r / a.HH;
-      const int id = jd0 + hd, ih = jh0 + hh, iw = jw0 + hw;
-      const bool ok = id >= 0 && id < a.ID && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW && !(cin4 && piece);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        const size_t vox = (size_t)((n * a.ID + id) * a.IH + ih) * a.IW + iw;
-        v = *reinterpret_cast<const float4*>(xb + vox * cx + cofs + piece * 4);
-        if (PRO) {
-          const float4 s4 = *reinterpret_cast<const float4*>(a.sc + (size_t)n * Cin + ci0 + piece * 4);
-          const float4 h4 = *reinterpret_cast<const float4*>(a.sh + (size_t)n * Cin + ci0 + piece * 4);
-          v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
-          v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+    // (four slots per trip with their loads issued together, as in k_conv_f32_mfma; a thread's piece is fixed)
+    {
+      constexpr int PV = CI / 4;
+      const int piece = tid % PV;
+      for (int i0 = tid; i0 < HV * PV; i0 += 1024) {
+        float4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int u = (i0 + k * 256) / PV;
+          const int hw = u % a.HW, r = u / a.HW, hh = r % a.HH, hd = r / a.HH;
+          const int id = jd0 + hd, ih = jh0 + hh, iw = jw0 + hw;
+          ok[k] = u < HV && id >= 0 && id < a.ID && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW && !(cin4 && piece);
+          const size_t vox = ok[k] ? (size_t)((n * a.ID + id) * a.IH + ih) * a.IW + iw : 0;
+          v[k] = *reinterpret_cast<const float4*>(xb + (ok[k] ? vox * cx + cofs + piece * 4 : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int u = (i0 + k * 256) / PV;
+          float4 o = v[k];
+          if (PRO) {
+            o.x = fmaxf(fmaf(o.x, s4.x, h4.x), 0.f); o.y = fmaxf(fmaf(o.y, s4.y, h4.y), 0.f);
+            o.z = fmaxf(fmaf(o.z, s4.z, h4.z), 0.f); o.w = fmaxf(fmaf(o.w, s4.w, h4.w), 0.f);
+          }
+          if (!ok[k]) o = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (u < HV) *reinterpret_cast<float4*>(xl + (size_t)u * PX + piece * 4) = o;
         }
       }
-      *reinterpret_cast<float4*>(xl + (size_t)u * PX + piece * 4) = v;
     }
     // ---- dy tile, CO channels (channels >= Cout and voxels outside the tensor are zero)
-    for (int i = tid; i < NV * (CO / 4); i += 256) {
-      const int v_ = i / (CO / 4), piece = i % (CO / 4);
-      const int l = v_ & 15, row = v_ >> 4, lth = row % TH, ltd = row / TH;
-      const int od = od0 + ltd, oh = oh0 + lth, ow = ow0 + l;
-      const int co = co0 + piece * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (od < a.OD && oh < a.OH && ow < a.OW && co < a.Cout) {
-        const size_t vox = (size_t)((n * a.OD + od) * a.OH + oh) * a.OW + ow;
-        v = *reinterpret_cast<const float4*>(a.dy + vox * a.Cout + co);
+    {
+      constexpr int PV = CO / 4;
+      const int piece = tid % PV, co = co0 + piece * 4;
+      for (int i0 = tid; i0 < NV * PV; i0 += 1024) {
+        float4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int v_ = (i0 + k * 256) / PV;
+          const int l = v_ & 15, row = v_ >> 4, lth = row % TH, ltd = row / TH;
+          const int od = od0 + ltd, oh = oh0 + lth, ow = ow0 + l;
+          ok[k] = v_ < NV && od < a.OD && oh < a.OH && ow < a.OW && co < a.Cout;
+          const size_t vox = ok[k] ? (size_t)((n * a.OD + od) * a.OH + oh) * a.OW + ow : 0;
+          v[k] = *reinterpret_cast<const float4*>(a.dy + (ok[k] ? vox * a.Cout + co : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int v_ = (i0 + k * 256) / PV;
+          if (v_ < NV) *reinterpret_cast<float4*>(yl + v_ * PY + piece * 4) = ok[k] ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
-      *reinterpret_cast<float4*>(yl + v_ * PY + piece * 4) = v;
     }
     __syncthreads();
     if (a.bpart && blockIdx.z == 0) {
