@@ -345,7 +345,7 @@ namespace devis {
 int convT_fwd_f32_mfma(const devis_convT_desc*, const void*, const void*, const float*, void*, hipStream_t);
 int convT_dgrad_f32_mfma(const devis_convT_desc*, const void*, const void*, void*, hipStream_t);
 size_t convT_wgrad_f32_workspace(const devis_convT_desc*);
-int convT_wgrad_f32_mfma(const devis_convT_desc*, const void*, const void*, float*, void*, size_t, hipStream_t);
+int convT_wgrad_f32_mfma(const devis_convT_desc*, const void*, const void*, float*, float*, bool*, void*, size_t, hipStream_t);
 }  // namespace devis
 
 using namespace devis;
@@ -397,7 +397,9 @@ int devis_convT_wgrad(const devis_convT_desc* d, const void* x, const void* dy, 
   hipStream_t s = (hipStream_t)stream;
   const int Tn = p.KD * p.KH * p.KW;
   const int64_t IV = p.N * p.ID * p.IH * p.IW;
-  int rc = convT_wgrad_f32_mfma(d, x, dy, dw, workspace, workspace_bytes, s);     // fp32 on the matrix cores (dw only)
+  bool bias_done = false;
+  int rc = convT_wgrad_f32_mfma(d, x, dy, dw, dbias, &bias_done, workspace, workspace_bytes, s);   // fp32 on the matrix cores
+  if (bias_done) return rc;
   if (rc == DEVIS_ERR_UNSUPPORTED) {
     rc = check_hip(hipMemsetAsync(dw, 0, sizeof(float) * p.Cin * p.Cout * Tn, s));
     if (rc) return rc;

@@ -629,6 +629,29 @@ int conv_wgrad_f32_mfma(const devis_conv_desc* d, const void* x1, const void* x2
   return launch_reduce_partials(r, s);
 }
 
+// Column sums of a [rows][C] fp32 matrix in a fixed order (the bias gradient of a transposed convolution: its dy is not
+// an operand the weight-gradient kernel stages as "dy").  C a power of two <= 256.  Block b sums its share of the rows
+// per channel (256 / C threads per channel, combined through LDS in thread order) into bpart[b][C]; k_reduce_partials
+// adds the blocks.
+__global__ void __launch_bounds__(256)
+k_colsum_det(const float* __restrict__ x, int64_t rows, int C, int64_t rows_per_block, float* __restrict__ bpart) {
+  __shared__ float red[256];
+  const int c = threadIdx.x % C, sub = threadIdx.x / C, nsub = 256 / C;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float acc = 0.f;
+  for (int64_t r = r0 + sub; r < r1; r += nsub) acc += x[r * C + c];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int k = 0; k < nsub; ++k) t += red[k * C + threadIdx.x];
+    bpart[(size_t)blockIdx.x * C + threadIdx.x] = t;
+  }
+}
+static bool colsum_det_ok(int64_t C) { return C >= 1 && C <= 256 && (C & (C - 1)) == 0; }
+static const int COLSUM_BLOCKS = 1024;
+
 // Weight gradient of the transposed convolution (kernel == stride): dW[ci][co][t] = sum_i x[i][ci] dy[K i + t][co] is
 // the weight gradient of the convolution dy -> x with kernel = stride = K (its "input" is dy, its "output gradient" x),
 // and the reduction's [cout'][cin'][T] order is PyTorch's [Cin][Cout][T].  The bias gradient (a column sum of dy) is
@@ -644,13 +667,36 @@ static bool convT_as_conv(const devis_convT_desc* d, devis_conv_desc* c) {
 }
 size_t convT_wgrad_f32_workspace(const devis_convT_desc* d) {
   devis_conv_desc c;
-  return convT_as_conv(d, &c) ? conv_wgrad_f32_workspace(&c) : 0;
+  if (!convT_as_conv(d, &c)) return 0;
+  const size_t w = conv_wgrad_f32_workspace(&c);
+  return w ? w + (size_t)COLSUM_BLOCKS * d->Cout * sizeof(float) : 0;
 }
-int convT_wgrad_f32_mfma(const devis_convT_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,
-                         hipStream_t s) {
+// dbias: written here (fixed-order column sums of dy) when the channel count allows, else *bias_done stays false and
+// the caller sums it its own way.
+int convT_wgrad_f32_mfma(const devis_convT_desc* d, const void* x, const void* dy, float* dw, float* dbias, bool* bias_done,
+                         void* ws, size_t ws_bytes, hipStream_t s) {
   devis_conv_desc c;
+  *bias_done = false;
   if (!convT_as_conv(d, &c)) return DEVIS_ERR_UNSUPPORTED;
-  return conv_wgrad_f32_mfma(&c, dy, nullptr, nullptr, nullptr, x, dw, nullptr, ws, ws_bytes, s);
+  const size_t wbytes = conv_wgrad_f32_workspace(&c);
+  if (!wbytes) return DEVIS_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < wbytes + (size_t)COLSUM_BLOCKS * d->Cout * sizeof(float)) return DEVIS_ERR_WORKSPACE;
+  int rc = conv_wgrad_f32_mfma(&c, dy, nullptr, nullptr, nullptr, x, dw, nullptr, ws, wbytes, s);
+  if (rc || !dbias || !colsum_det_ok(d->Cout)) return rc;
+  const int64_t rows = d->N * d->ID * d->KD * d->IH * d->KH * d->IW * d->KW;
+  const int64_t rpb = cdiv(rows, COLSUM_BLOCKS);
+  const int blocks = (int)cdiv(rows, rpb);
+  float* bpart = reinterpret_cast<float*>((char*)ws + wbytes);
+  hipLaunchKernelGGL(k_colsum_det, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, rows, (int)d->Cout, rpb, bpart);
+  rc = launch_status();
+  if (rc) return rc;
+  RedArgs r;
+  r.part = bpart; r.bpart = bpart; r.dw = dbias; r.dbias = dbias;
+  r.nparts = 0; r.nbparts = blocks; r.Cb = (int)d->Cout;
+  r.pstride = 0; r.total = 0; r.mode = RED_CONV3; r.A = 1; r.B = 1; r.cin_real = 1;
+  rc = launch_reduce_partials(r, s);
+  *bias_done = rc == DEVIS_OK;
+  return rc;
 }
 
 }  // namespace devis
