@@ -12,8 +12,9 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--model", default="U")
 ap.add_argument("--patch-batch", type=int, default=1)
 ap.add_argument("--graph-streams", type=int, default=0)
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
 a = ap.parse_args()
-args = bench.brats_args(torch.bfloat16); args.model_name = a.model
+args = bench.brats_args(torch.bfloat16 if a.dtype == "bf16" else torch.float32); args.model_name = a.model
 torch.manual_seed(0)
 m = TMSU(args).eval()
 g = torch.Generator().manual_seed(1234)
@@ -30,6 +31,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     out = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"workload": "configs[4]: sliding-window inference, 1 GPU, 4x240x240x160 volume = 8 patches of 128^3, model %s bf16, patch_batch %d, graph_streams %d" % (a.model, a.patch_batch, a.graph_streams),
+print(json.dumps({"workload": "configs[4]: sliding-window inference, 1 GPU, 4x240x240x160 volume = 8 patches of 128^3, model %s %s, patch_batch %d, graph_streams %d" % (a.model, a.dtype, a.patch_batch, a.graph_streams),
                   "ms_per_volume": dt * 1e3, "volumes_per_s": 1 / dt, "patch_voxels_per_s": 8 * 128 ** 3 / dt,
                   "outputs": sorted(k for k, v in out.items() if v is not None)}))
