@@ -228,6 +228,11 @@ static int run_f32(F32ConvArgs& a, hipStream_t s) {
       (int64_t)a.N * a.YD * a.YH * a.YW >= ((int64_t)1 << 31))
     return DEVIS_ERR_UNSUPPORTED;
   const bool strided = a.SD > 1 || a.SH > 1 || a.SW > 1;
+  if (a.OD == 1) {                                     // the 2-D nets: a second plane in the tile would be idle
+    if (a.Cout >= 32) return launch_f32<2, 1, 8>(a, s);
+    if (strided) return launch_f32<1, 1, 8>(a, s);
+    return launch_f32<1, 1, 16>(a, s);
+  }
   if (a.Cout >= 32) return launch_f32<2, 2, 4>(a, s);
   if (strided) return launch_f32<1, 2, 4>(a, s);       // an 8-row tile of a stride-2 layer does not fit the LDS
   return launch_f32<1, 2, 8>(a, s);
@@ -355,6 +360,17 @@ int convT_dgrad_f32_mfma(const devis_convT_desc* d, const void* dy, const void* 
 // [part][T][Cout][Cin16] are summed in a fixed order by k_reduce_partials (wgrad_reduce.h), which also scatters into
 // the PyTorch layout; the bias gradient is summed per block from the staged dy tile and reduced by the same launch.
 
+// four consecutive floats of which only the first `nvalid` (0 .. 4) exist; `vec`: nvalid is 0 or 4 and p is 16-byte aligned
+__device__ __forceinline__ float4 ld4_masked(const float* p, int nvalid, bool vec) {
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid > 0) r.x = p[0];
+  if (nvalid > 1) r.y = p[1];
+  if (nvalid > 2) r.z = p[2];
+  if (nvalid > 3) r.w = p[3];
+  return r;
+}
+
 struct F32WgArgs {
   const float* x1;
   const float* x2;
@@ -392,11 +408,12 @@ k_wgrad_f32_mfma(F32WgArgs a) {
   const int dci = sb % a.ndc;
   const int n = sb / a.ndc;
   const int co0 = blockIdx.y * CO, ci0 = blockIdx.z * CI;
-  const bool cin4 = a.C1 == 4;
-  const int Cin = cin4 ? 4 : a.C1 + a.C2;
-  const bool second = !cin4 && ci0 >= a.C1;                   // a slab lies in ONE input (C1 is a multiple of CI: host)
+  const bool csmall = a.C1 < 16;                              // ONE input of fewer than 16 channels, zero-extended
+  const int Cin = csmall ? a.C1 : a.C1 + a.C2;
+  const bool second = !csmall && ci0 >= a.C1;                 // a slab lies in ONE input (C1 is a multiple of CI: host)
   const float* xb = second ? a.x2 : a.x1;
   const int cx = second ? a.C2 : a.C1, cofs = second ? ci0 - a.C1 : ci0;
+  const bool xvec = (cx & 3) == 0, yvec = (a.Cout & 3) == 0;  // else: scalar loads of the channels that exist
 
   const int HV = a.HD * a.HH * a.HW;
   float* xl = reinterpret_cast<float*>(smem);
@@ -427,6 +444,7 @@ k_wgrad_f32_mfma(F32WgArgs a) {
     {
       constexpr int PV = CI / 4;
       const int piece = tid % PV;
+      const int xn = min(max(cx - cofs - piece * 4, 0), 4);  // channels of this piece that exist
       for (int i0 = tid; i0 < HV * PV; i0 += 1024) {
         float4 v[4];
         bool ok[4];
@@ -435,9 +453,9 @@ k_wgrad_f32_mfma(F32WgArgs a) {
           const int u = (i0 + k * 256) / PV;
           const int hw = u % a.HW, r = u / a.HW, hh = r % a.HH, hd = r / a.HH;
           const int id = jd0 + hd, ih = jh0 + hh, iw = jw0 + hw;
-          ok[k] = u < HV && id >= 0 && id < a.ID && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW && !(cin4 && piece);
+          ok[k] = u < HV && id >= 0 && id < a.ID && ih >= 0 && ih < a.IH && iw >= 0 && iw < a.IW && xn > 0;
           const size_t vox = ok[k] ? (size_t)((n * a.ID + id) * a.IH + ih) * a.IW + iw : 0;
-          v[k] = *reinterpret_cast<const float4*>(xb + (ok[k] ? vox * cx + cofs + piece * 4 : 0));
+          v[k] = ld4_masked(xb + (ok[k] ? vox * cx + cofs + piece * 4 : 0), ok[k] ? xn : (xvec ? 4 : 0), xvec);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -456,6 +474,7 @@ k_wgrad_f32_mfma(F32WgArgs a) {
     {
       constexpr int PV = CO / 4;
       const int piece = tid % PV, co = co0 + piece * 4;
+      const int yn = min(max(a.Cout - co, 0), 4);
       for (int i0 = tid; i0 < NV * PV; i0 += 1024) {
         float4 v[4];
         bool ok[4];
@@ -464,9 +483,9 @@ k_wgrad_f32_mfma(F32WgArgs a) {
           const int v_ = (i0 + k * 256) / PV;
           const int l = v_ & 15, row = v_ >> 4, lth = row % TH, ltd = row / TH;
           const int od = od0 + ltd, oh = oh0 + lth, ow = ow0 + l;
-          ok[k] = v_ < NV && od < a.OD && oh < a.OH && ow < a.OW && co < a.Cout;
+          ok[k] = v_ < NV && od < a.OD && oh < a.OH && ow < a.OW && yn > 0;
           const size_t vox = ok[k] ? (size_t)((n * a.OD + od) * a.OH + oh) * a.OW + ow : 0;
-          v[k] = *reinterpret_cast<const float4*>(a.dy + (ok[k] ? vox * a.Cout + co : 0));
+          v[k] = ld4_masked(a.dy + (ok[k] ? vox * a.Cout + co : 0), ok[k] ? yn : (yvec ? 4 : 0), yvec);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -533,9 +552,8 @@ static bool f32_wgrad_plan(const devis_conv_desc* d, F32WgPlan* p) {
   const bool k122 = d->KD == 1 && d->KH == 2 && d->KW == 2;
   if (!(k333 || k133 || k111 || k222 || k122)) return false;
   if (d->SD < 1 || d->SD > 2 || d->SH < 1 || d->SH > 2 || d->SW < 1 || d->SW > 2) return false;
-  const bool first = d->C1 == 4 && d->C2 == 0;
+  const bool first = d->C1 < 16 && d->C2 == 0;                // one input of fewer than 16 channels: zero-extended
   if (!first && (d->C1 % 16 || d->C2 % 16)) return false;
-  if (d->Cout % 4) return false;
   if (d->N * d->ID * d->IH * d->IW >= ((int64_t)1 << 31) || d->N * d->OD * d->OH * d->OW >= ((int64_t)1 << 31)) return false;
   const bool strided = d->SD > 1 || d->SH > 1 || d->SW > 1;
   const int64_t cin = d->C1 + d->C2;
@@ -544,6 +562,7 @@ static bool f32_wgrad_plan(const devis_conv_desc* d, F32WgPlan* p) {
   else if (strided && d->Cout >= 32 && d->Cout % 32 == 0) { p->no = 2; p->ni = 1; p->td = 2; p->th = 4; }
   else if (strided) { p->no = 1; p->ni = 1; p->td = 2; p->th = 4; }
   else { p->no = 1; p->ni = 1; p->td = 2; p->th = 8; }
+  if (d->OD == 1 && d->KD == 1) { p->td = 1; p->th *= 2; }     // the 2-D nets: one plane, twice the rows
   p->nk = 4 / (p->no * p->ni);
   F32WgArgs& a = p->a;
   a.N = (int)d->N; a.ID = (int)d->ID; a.IH = (int)d->IH; a.IW = (int)d->IW; a.OD = (int)d->OD; a.OH = (int)d->OH; a.OW = (int)d->OW;
@@ -598,10 +617,18 @@ static int launch_wg_f32(const F32WgPlan& p, hipStream_t s) {
 #define WGF(NO, NI, TD, TH) \
   if (p.no == NO && p.ni == NI && p.td == TD && p.th == TH) \
     return a.sc ? go(k_wgrad_f32_mfma<KD, KH, KW, NO, NI, TD, TH, true>) : go(k_wgrad_f32_mfma<KD, KH, KW, NO, NI, TD, TH, false>)
-  WGF(2, 2, 2, 4);
-  WGF(2, 1, 2, 4);
-  WGF(1, 1, 2, 4);
-  WGF(1, 1, 2, 8);
+  if constexpr (KD == 1) {                             // one-plane tiles of the 2-D nets
+    WGF(2, 2, 1, 8);
+    WGF(2, 1, 1, 8);
+    WGF(1, 1, 1, 8);
+    WGF(1, 1, 1, 16);
+  }
+  if constexpr (KD > 1 || (KH == 1 && KW == 1)) {
+    WGF(2, 2, 2, 4);
+    WGF(2, 1, 2, 4);
+    WGF(1, 1, 2, 4);
+    WGF(1, 1, 2, 8);
+  }
 #undef WGF
   return DEVIS_ERR_UNSUPPORTED;
 }
@@ -610,6 +637,7 @@ int conv_wgrad_f32_mfma(const devis_conv_desc* d, const void* x1, const void* x2
                         const void* dy, float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
   F32WgPlan p;
   if (!f32_wgrad_plan(d, &p)) return DEVIS_ERR_UNSUPPORTED;
+  if (d->C1 < 16 && sc) return DEVIS_ERR_UNSUPPORTED;         // the prologue reads its coefficients four at a time
   if (!ws || ws_bytes < p.total_bytes) return DEVIS_ERR_WORKSPACE;
   F32WgArgs& a = p.a;
   a.x1 = (const float*)x1; a.x2 = (const float*)x2; a.dy = (const float*)dy; a.sc = sc; a.sh = sh;
@@ -625,7 +653,7 @@ int conv_wgrad_f32_mfma(const devis_conv_desc* d, const void* x1, const void* x2
   r.part = a.part; r.bpart = a.bpart; r.dw = dw; r.dbias = dbias;
   r.nparts = (int)(p.nspatial * p.nk); r.nbparts = (int)p.nspatial; r.Cb = a.Cout;
   r.pstride = a.pstride; r.total = a.pstride;
-  r.mode = RED_CONV3; r.A = a.Cout; r.B = a.cin16; r.cin_real = a.C1 == 4 ? 4 : a.cin16;
+  r.mode = RED_CONV3; r.A = a.Cout; r.B = a.cin16; r.cin_real = a.C1 < 16 ? a.C1 : a.cin16;
   return launch_reduce_partials(r, s);
 }
 

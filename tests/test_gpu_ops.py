@@ -565,11 +565,14 @@ def test_batch_weight_packing_equals_the_per_tensor_calls(dtype):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 0, 16, (12, 20, 36), (3, 3, 3), (1, 1, 1)), (1, 32, 32, 64, (6, 10, 18), (1, 1, 1), (1, 1, 1)),
-                                  (2, 16, 0, 32, (11, 9, 20), (3, 3, 3), (2, 2, 2)), (1, 64, 0, 64, (5, 6, 20), (3, 3, 3), (1, 1, 1))])
+                                  (2, 16, 0, 32, (11, 9, 20), (3, 3, 3), (2, 2, 2)), (1, 64, 0, 64, (5, 6, 20), (3, 3, 3), (1, 1, 1)),
+                                  (3, 1, 0, 32, (1, 20, 24), (1, 3, 3), (1, 1, 1)), (2, 3, 0, 32, (1, 12, 7), (1, 3, 3), (1, 1, 1)),
+                                  (2, 32, 0, 2, (1, 16, 24), (1, 1, 1), (1, 1, 1)), (2, 32, 32, 32, (1, 20, 40), (1, 3, 3), (1, 1, 1))])
 def test_fp32_weight_gradient_is_deterministic(case):
     """The fp32 parity mode's weight gradients (csrc/conv_f32_mfma.hip) are sums in a fixed order: two calls on the same
     inputs give the same bits (the generic kernels they replaced accumulated with float atomics), for every slab
-    configuration of the kernel (16 x 16 with the waves splitting K, 2 x 2 slabs, strided, two inputs)."""
+    configuration of the kernel (16 x 16 with the waves splitting K, 2 x 2 slabs, strided, two inputs; the 2-D nets'
+    one-plane tiles, their 1- and 3-channel first layers and 2-class head - no prologue on the thin inputs)."""
     from devis_amd import ops
     n, c1, c2, co, sp, k, s = case
     g = torch.Generator().manual_seed(11)
@@ -580,11 +583,15 @@ def test_fp32_weight_gradient_is_deterministic(case):
     dy = torch.randn((n,) + osp + (co,), generator=g).cuda()
     sc = (torch.rand((n, c1 + c2), generator=g) + 0.5).cuda()
     sh = torch.randn((n, c1 + c2), generator=g).cuda()
+    if c1 < 16:                                     # first layers have no norm in front of them
+        sc, sh = None, None
     runs = [ops.conv_wgrad(x1, x2, dy, geom, (co, c1 + c2) + k, sc, sh) for _ in range(3)]
     for dw, db in runs[1:]:
         assert torch.equal(dw, runs[0][0]) and torch.equal(db, runs[0][1])
     # and they are the right numbers
-    xa = torch.relu(torch.cat([t for t in (x1, x2) if t is not None], -1) * sc[:, None, None, None, :] + sh[:, None, None, None, :])
+    xa = torch.cat([t for t in (x1, x2) if t is not None], -1)
+    if sc is not None:
+        xa = torch.relu(xa * sc[:, None, None, None, :] + sh[:, None, None, None, :])
     w = torch.zeros((co, c1 + c2) + k, device="cuda", requires_grad=True)
     b = torch.zeros((co,), device="cuda", requires_grad=True)
     F.conv3d(xa.permute(0, 4, 1, 2, 3), w, b, stride=s, padding=tuple(kk // 2 for kk in k)).backward(dy.permute(0, 4, 1, 2, 3))
