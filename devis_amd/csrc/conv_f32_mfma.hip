@@ -395,6 +395,7 @@ k_wgrad_f32_mfma(F32WgArgs a) {
   constexpr int CI = NI * 16, CO = NO * 16;
   constexpr int PX = CI == 32 ? 48 : 16, PY = CO == 32 ? 48 : 16;   // pitches (floats): lane quads on distinct banks
   constexpr int NV = TD * TH * 16, NSTEPS = NV / 4;
+  constexpr int SB = 4;                                       // x-tile slots a thread loads per trip (1 measured the same)
   static_assert(NSLAB == 1 || NSLAB == 2 || NSLAB == 4, "slabs per block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -440,16 +441,16 @@ k_wgrad_f32_mfma(F32WgArgs a) {
     const int jd0 = od0 * a.SD - a.PD;
     if (tdi > td_begin) __syncthreads();                      // the previous tile's fragments are read
     // ---- x halo tile, CI channels: CI / 4 pieces of 16 bytes per voxel
-    // (four slots per trip with their loads issued together, as in k_conv_f32_mfma; a thread's piece is fixed)
+    // (SB slots per trip with their loads issued together, as in k_conv_f32_mfma; a thread's piece is fixed)
     {
       constexpr int PV = CI / 4;
       const int piece = tid % PV;
       const int xn = min(max(cx - cofs - piece * 4, 0), 4);  // channels of this piece that exist
-      for (int i0 = tid; i0 < HV * PV; i0 += 1024) {
-        float4 v[4];
-        bool ok[4];
+      for (int i0 = tid; i0 < HV * PV; i0 += SB * 256) {
+        float4 v[SB];
+        bool ok[SB];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SB; ++k) {
           const int u = (i0 + k * 256) / PV;
           const int hw = u % a.HW, r = u / a.HW, hh = r % a.HH, hd = r / a.HH;
           const int id = jd0 + hd, ih = jh0 + hh, iw = jw0 + hw;
@@ -458,7 +459,7 @@ k_wgrad_f32_mfma(F32WgArgs a) {
           v[k] = ld4_masked(xb + (ok[k] ? vox * cx + cofs + piece * 4 : 0), ok[k] ? xn : (xvec ? 4 : 0), xvec);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SB; ++k) {
           const int u = (i0 + k * 256) / PV;
           float4 o = v[k];
           if (PRO) {
