@@ -1,7 +1,7 @@
 // MFMA 3x3x3 convolution for the deep, small-volume layers (64 channels at 32^3, 128 channels at 16^3; bf16,
 // channels-last, stride 1, gfx950), third design: WEIGHTS STATIONARY IN REGISTERS, K SPLIT OVER THE WAVES.
 //
-// conv_deep.hip / conv_deep64.hip stream both operands through LDS per 32-channel K chunk: every MFMA needs about one
+// The r02 kernels it replaces (conv_deep.hip / conv_deep64.hip, deleted) streamed both operands through LDS per 32-channel K chunk: every MFMA needed about one
 // 1 KB LDS fragment read (twice what the LDS can deliver at the matrix rate), and every chunk pays two barriers and a
 // staging pass with one wave per SIMD (16-18 us / 26-30 us per launch for 2.9 / 5.8 us of matrix time).  Here
 //   * the block's activation halo tile (ALL input channels) is staged into LDS once - one barrier for the whole K loop;

@@ -544,7 +544,7 @@ k_norm_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x, const float*
 #pragma unroll
           for (int j = 0; j < VN; ++j) {
             float gm = fmaf(xv[k][j], scv[j], shv[j]) > 0.f ? g[k][j] : 0.f;
-#ifdef DEVIS_PK_NOP      // diagnostic build only (tools/race_probe5.py): two wait states between the
+#ifdef DEVIS_PK_NOP      // diagnostic build only (tools/race_probe.py packed): two wait states between the
             asm volatile("s_nop 1" : "+v"(gm));      // select that writes gm and the packed FMA that reads it
 #endif
             float t = fmaf(av[j], gm, fmaf(bv[j], xv[k][j], cv[j]));
