@@ -56,8 +56,9 @@ class _Up(nn.Module):                          # VNet2D.py:94-118
 class _RunV2d:
     """Forward / backward schedule of the 2-D V-Net over channels-last (N, H, W, C) tensors."""
 
-    def __init__(self, params, dtype, tape):
+    def __init__(self, params, dtype, tape, packed):
         self.P = params
+        self.W = packed                       # name.weight -> [w_packed, w_dgrad | None] (ops.WeightPacker: one launch)
         self.dtype, self.taping = dtype, tape
         self.tape: List = []
         self.grads: Dict[str, Tensor] = {}
@@ -66,6 +67,12 @@ class _RunV2d:
     def _push(self, *e):
         if self.taping:
             self.tape.append(e)
+
+    def _w(self, name):
+        return self.W[name + ".weight"][0]
+
+    def _wd(self, name):
+        return self.W[name + ".weight"][1]
 
     def _gn(self, name, x, partials=None):
         return ops.gn_stats(x, self.P[name + ".weight"], self.P[name + ".bias"], groups=GROUPS, partials=partials)
@@ -77,7 +84,7 @@ class _RunV2d:
         stages, h, p = [], x, pro
         for i in range(n_stages):
             cn, gn = "%s.conv.%d" % (name, 3 * i), "%s.conv.%d" % (name, 3 * i + 1)
-            w = ops.pack_conv_weight(self.P[cn + ".weight"], self.dtype)
+            w = self._w(cn)
             raw, part = ops.conv_fwd(h, None, w, self.P[cn + ".bias"], C3, p[0] if p else None, p[1] if p else None,
                                      want_stats=True)
             st = self._gn(gn, raw, part)
@@ -90,7 +97,7 @@ class _RunV2d:
     def down(self, name, x):
         if x.shape[1] % 2 or x.shape[2] % 2:                 # k2 s2 p0 drops an odd last row / column
             x = x[:, :x.shape[1] // 2 * 2, :x.shape[2] // 2 * 2, :].contiguous()
-        w = ops.pack_conv_weight(self.P[name + ".conv.0.weight"], self.dtype)
+        w = self._w(name + ".conv.0")
         raw = ops.conv_fwd(x, None, w, self.P[name + ".conv.0.bias"], C2S2)
         st = self._gn(name + ".conv.1", raw)
         self._push("vdown", name, x, raw, st, w)
@@ -99,7 +106,7 @@ class _RunV2d:
     def up(self, name, x, skip, up_first: bool):
         """relu(gn(convT(x))) combined with `skip` by offsetAdd.  up_first: offsetAdd(up, skip) - the reference then
         pads the SKIP (VNet2D.py:220,224), which can only work when the widths already agree."""
-        wt = ops.pack_convT_weight(self.P[name + ".conv.0.weight"], self.dtype)
+        wt = self._w(name + ".conv.0")
         raw = ops.convT_fwd(x, wt, self.P[name + ".conv.0.bias"], (2, 2))
         st = self._gn(name + ".conv.1", raw)
         h, w = raw.shape[1], raw.shape[2]
@@ -135,7 +142,7 @@ class _RunV2d:
         x7 = self.conv_block("block_seven", self.up("block_six_up", x6, x3, False), 3)
         x8 = self.conv_block("block_eight", self.up("block_seven_up", x7, x2, True), 2)
         x9 = self.conv_block("block_nine", self.up("block_eight_up", x8, x1, True), 2)
-        wp = ops.pack_conv_weight(self.P["out_conv.weight"], self.dtype)
+        wp = self._w("out_conv")
         out = ops.conv_fwd(x9, None, wp, self.P["out_conv.bias"], C1)
         self._push("out", x9, wp)
         return out
@@ -169,9 +176,9 @@ class _RunV2d:
                 ops.conv_wgrad, h_in, None, draw, C3, P[cn + ".weight"].shape, p_in[0] if p_in else None,
                 p_in[1] if p_in else None)
             if p_in is not None:
-                d, _, pt = ops.conv_dgrad(draw, w, C3, h_in.shape, norm=(h_in, p_in[0], p_in[1]))
+                d, _, pt = ops.conv_dgrad(draw, w, C3, h_in.shape, wd=self._wd(cn), norm=(h_in, p_in[0], p_in[1]))
             elif i > 0 or need_dx:
-                d, pt = ops.conv_dgrad(draw, w, C3, h_in.shape)[0], None
+                d, pt = ops.conv_dgrad(draw, w, C3, h_in.shape, wd=self._wd(cn))[0], None
             else:
                 d, pt = None, None
         return d, pt
@@ -184,8 +191,8 @@ class _RunV2d:
             d_act, raw, st[0], st[1], P[gn + ".weight"], st[2], st[3], GROUPS, False, partials=pt)
         g[cn + ".weight"], g[cn + ".bias"] = self._wg(ops.conv_wgrad, x, None, draw, C2S2, P[cn + ".weight"].shape)
         if tuple(x.shape) == tuple(full_shape):
-            return ops.conv_dgrad(draw, w, C2S2, x.shape, residual=skip)[0]
-        dx = ops.conv_dgrad(draw, w, C2S2, x.shape)[0]           # an odd row / column the conv dropped: skip gradient only
+            return ops.conv_dgrad(draw, w, C2S2, x.shape, residual=skip, wd=self._wd(cn))[0]
+        dx = ops.conv_dgrad(draw, w, C2S2, x.shape, wd=self._wd(cn))[0]           # an odd row / column the conv dropped: skip gradient only
         out = skip.clone()
         out[:, :x.shape[1], :x.shape[2], :] = ops.add(dx, skip[:, :x.shape[1], :x.shape[2], :].contiguous())
         return out
@@ -200,7 +207,7 @@ class _RunV2d:
         draw, g[gn + ".weight"], g[gn + ".bias"] = ops.norm_relu_bwd(
             d_up, raw, st[0], st[1], P[gn + ".weight"], st[2], st[3], GROUPS, False)
         g[cn + ".weight"], g[cn + ".bias"] = self._wg(ops.convT_wgrad, x, draw, (2, 2), P[cn + ".weight"].shape)
-        return ops.convT_dgrad(draw, wt, (2, 2), x.shape), d_out
+        return ops.convT_dgrad(draw, wt, (2, 2), x.shape, wt=self._wd(cn)), d_out
 
     def backward(self, dlogits, need_dx):
         from .unet3d import _side_events, _side_stream
@@ -211,7 +218,7 @@ class _RunV2d:
         _, x9, wp = self.tape.pop()
         self.grads["out_conv.weight"], self.grads["out_conv.bias"] = self._wg(
             ops.conv_wgrad, x9, None, dlogits, C1, self.P["out_conv.weight"].shape)
-        d = ops.conv_dgrad(dlogits, wp, C1, x9.shape)[0]
+        d = ops.conv_dgrad(dlogits, wp, C1, x9.shape, wd=self._wd("out_conv"))[0]
         skips = []
         for _ in range(4):                                   # block_nine / eight / seven / six + their up convs
             d, _ = self._vblock_bwd(d)
@@ -233,7 +240,8 @@ class _VNet2dFn(torch.autograd.Function):
     def forward(ctx, model, x, *params):
         names = model._param_names
         taping = any(ctx.needs_input_grad)
-        run = _RunV2d(dict(zip(names, params)), model.compute_dtype, taping)
+        P = dict(zip(names, params))
+        run = _RunV2d(P, model.compute_dtype, taping, model._packed(P))
         logits = run.forward(ops.to_channels_last(x, model.compute_dtype))
         ctx.run, ctx.names, ctx.need_dx = run, names, ctx.needs_input_grad[1]
         return logits
@@ -283,6 +291,17 @@ class VNet2D(nn.Module):
         self.compute_dtype = compute_dtype
         self.in_ch, self.num_classes = n_channels, n_classes
         self._param_names = [n for n, _ in self.named_parameters()]
+        self._conv_modules = [(n + ".weight", m) for n, m in self.named_modules()
+                              if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+        self._packer = None
+
+    def _packed(self, P):
+        """All conv weights in the kernels' layouts by ONE launch per step (ops.WeightPacker), as the other nets."""
+        ent = [(n, P[n].detach(), "convT" if isinstance(m, nn.ConvTranspose2d) else "conv") for n, m in self._conv_modules]
+        key = tuple(w.data_ptr() for _, w, _ in ent) + (self.compute_dtype,)
+        if self._packer is None or self._packer.key != key:
+            self._packer = ops.WeightPacker(ent, self.compute_dtype, ent[0][1].device)
+        return self._packer.pack()
 
     def forward_channels_last(self, x):
         if x.dim() != 4 or x.shape[1] != self.in_ch:
