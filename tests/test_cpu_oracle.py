@@ -185,6 +185,36 @@ def test_library_exports_every_declared_symbol():
     assert lib.devis_evid_workspace_bytes(1, 8, 4) > 0       # pure host arithmetic, no GPU touched
 
 
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """include/devis_hip.h is the boundary a non-Python host binds: it must compile as C99, and a C
+    program that includes it must link against libdevis_hip.so and run its host-only entry points (no GPU touched)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "devis_amd")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "devis_hip.h")], check=True)
+    src = tmp_path / "host.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "devis_hip.h"\n'
+        "int main(void) {\n"
+        "  devis_conv_desc d = {0};\n"
+        "  d.N = 1; d.ID = d.IH = d.IW = 8; d.OD = d.OH = d.OW = 8; d.C1 = 16; d.Cout = 16;\n"
+        "  d.KD = d.KH = d.KW = 3; d.SD = d.SH = d.SW = 1; d.PD = d.PH = d.PW = 1; d.dtype = DEVIS_BF16;\n"
+        '  printf("%d %zu %zu\\n", devis_version(), devis_conv_wgrad_workspace_bytes(&d), devis_evid_workspace_bytes(1, 512, 4));\n'
+        "  return devis_conv_fwd(&d, 0, 0, 0, 0, 0, 0, 0, 0, 0) == DEVIS_ERR_BAD_ARG ? 0 : 1;\n"
+        "}\n")
+    exe = tmp_path / "host"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-I", inc, str(src), "-L", libdir, "-ldevis_hip", "-Wl,-rpath," + libdir,
+                    "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    ver, wg, ev = out.stdout.split()
+    assert int(ver) >= 101 and int(wg) > 0 and int(ev) > 0
+
+
 # ------------------------------------------------------------------ evaluation counts (§8(f)-3)
 def _evalmaps_case(golden, tag):
     import numpy as np
