@@ -296,6 +296,10 @@ def test_layout_roundtrip_and_add():
         assert torch.equal(ops.from_channels_last(y), x.to(dt).float())
         z = ops.add(y, y)
         assert torch.equal(z.float(), (y.float() * 2).to(dt).float())
+    # the 4-channel input of the 3-D nets has a kernel of its own in bf16 (one 8-byte store per voxel)
+    x4 = torch.randn((3, 4, 5, 7, 9), generator=g).cuda()
+    y4 = ops.to_channels_last(x4, torch.bfloat16)
+    assert torch.equal(y4.float(), x4.permute(0, 2, 3, 4, 1).to(torch.bfloat16).float())
 
 
 def test_bad_arguments_fail_loudly():
