@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Device memory of the bench step after four steps: reserved / allocated / peak, with the launch plan
+(DEVIS_LAUNCH_PLAN=1, default) or without (=0)."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 import bench
